@@ -1,0 +1,108 @@
+// fft512.hip.h — one 512-point complex FFT per 64-lane wavefront (gfx950).
+//
+// Replaces the cuFFT C2C calls of the reference (conv.cu:243, 367, 405, 407)
+// for the partition size of the uniform-partitioned engine.  512 = 8 x 8 x 8:
+// each lane holds 8 points in registers, does a radix-8 butterfly, and the two
+// digit exchanges between the three stages go through a wave-private LDS tile
+// whose rows are padded to 72 complex so that the transposed ds_read_b64 of a
+// 32-lane group lands on 32 distinct bank pairs.  Twiddles come from a 512-entry
+// table staged in LDS once per workgroup (computed in double on the host).
+//
+// Index algebra (n = 64 n2 + 8 n1 + n0, k = k0 + 8 k1 + 64 k2):
+//   X[k] = sum_n0 w8^(n0 k2) w64^(n0 k1) [ sum_n1 w8^(n1 k1) w512^((8 n1 + n0) k0)
+//            [ sum_n2 w8^(n2 k0) x[n] ] ]
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define FFT_N 512
+#define FFT_ROW 72                       // padded row length (complex) of the exchange tile
+#define FFT_WAVE_LDS (8 * FFT_ROW)       // complex entries of wave-private LDS (>= 512)
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -j (forward) or +j (inverse)
+template <int DIR>
+__device__ __forceinline__ float2 mulj(float2 a) {
+    return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+// 8-point DFT in registers, y[k] = sum_r v[r] exp(DIR * 2 pi i r k / 8)
+template <int DIR>
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    const float h = 0.70710678118654752440f;
+    // even / odd 4-point DFTs
+    float2 e0 = cadd(v[0], v[4]), e1 = csub(v[0], v[4]);
+    float2 e2 = cadd(v[2], v[6]), e3 = mulj<DIR>(csub(v[2], v[6]));
+    float2 E0 = cadd(e0, e2), E2 = csub(e0, e2), E1 = cadd(e1, e3), E3 = csub(e1, e3);
+    float2 o0 = cadd(v[1], v[5]), o1 = csub(v[1], v[5]);
+    float2 o2 = cadd(v[3], v[7]), o3 = mulj<DIR>(csub(v[3], v[7]));
+    float2 O0 = cadd(o0, o2), O2 = csub(o0, o2), O1 = cadd(o1, o3), O3 = csub(o1, o3);
+    // twiddles w8^k, k = 1..3
+    float2 t1, t3;
+    if (DIR < 0) {
+        t1 = make_float2((O1.x + O1.y) * h, (O1.y - O1.x) * h);    // * (1 - j)/sqrt2
+        t3 = make_float2((-O3.x + O3.y) * h, (-O3.y - O3.x) * h);  // * (-1 - j)/sqrt2
+    } else {
+        t1 = make_float2((O1.x - O1.y) * h, (O1.y + O1.x) * h);    // * (1 + j)/sqrt2
+        t3 = make_float2((-O3.x - O3.y) * h, (-O3.y + O3.x) * h);  // * (-1 + j)/sqrt2
+    }
+    float2 t2 = mulj<DIR>(O2);
+    v[0] = cadd(E0, O0);
+    v[4] = csub(E0, O0);
+    v[1] = cadd(E1, t1);
+    v[5] = csub(E1, t1);
+    v[2] = cadd(E2, t2);
+    v[6] = csub(E2, t2);
+    v[3] = cadd(E3, t3);
+    v[7] = csub(E3, t3);
+}
+
+template <int DIR>
+__device__ __forceinline__ float2 twiddle(const float2* tw, int idx) {
+    float2 w = tw[idx & (FFT_N - 1)];
+    if (DIR > 0) w.y = -w.y;
+    return w;
+}
+
+// In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in lds[0..511].
+// tw = LDS table exp(-2 pi i m / 512).  `lds` is wave-private (FFT_WAVE_LDS
+// entries).  All waves of the workgroup must call this the same number of
+// times (it contains workgroup barriers).
+template <int DIR>
+__device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* lds, const float2* tw, int lane) {
+    // stage 1: DFT over n2, twiddle w512^(lane * k0)
+    dft8<DIR>(v);
+#pragma unroll
+    for (int k0 = 1; k0 < 8; k0++) v[k0] = cmul(v[k0], twiddle<DIR>(tw, lane * k0));
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) lds[k0 * FFT_ROW + lane] = v[k0];
+    __syncthreads();
+    const int a = lane >> 3, n0 = lane & 7;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) v[n1] = lds[a * FFT_ROW + n1 * 8 + n0];
+    __syncthreads();
+    // stage 2: DFT over n1, twiddle w64^(n0 * k1)
+    dft8<DIR>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul(v[k1], twiddle<DIR>(tw, 8 * n0 * k1));
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) lds[a * FFT_ROW + k1 * 8 + n0] = v[k1];
+    __syncthreads();
+    // lane = 8 k0 + k1 now reads its 8 consecutive n0 values
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = lds[a * FFT_ROW + n0 * 8 + m];
+    __syncthreads();
+    // stage 3: DFT over n0 -> X[k0 + 8 k1 + 64 k2]
+    dft8<DIR>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) lds[a + 8 * n0 + 64 * k2] = v[k2];
+    __syncthreads();
+}
+
+// stage the twiddle table into LDS (all threads of the workgroup)
+__device__ __forceinline__ void load_twiddles(float2* s_tw, const float2* __restrict__ g_tw) {
+    for (int i = threadIdx.x; i < FFT_N; i += blockDim.x) s_tw[i] = g_tw[i];
+}

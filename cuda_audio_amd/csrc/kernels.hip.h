@@ -1,0 +1,518 @@
+// kernels.hip.h — the per-block hot path of the reference (conv.cu:287-466),
+// restructured as a uniform-partitioned overlap-add pipeline for gfx950.
+//
+// Data layout in HBM (all fp32; "bin" = one of 256 packed bins of a 512-point
+// real-signal spectrum, bin 0 packs {DC, Nyquist} which are both real):
+//   IR spectra   H[idx] : float4 [256 bins][Pstride]     {H_L.re, H_L.im, H_R.re, H_R.im}
+//   delay line   FDL    : float4 [256 bins][R slots]     {X_1.re, X_1.im, X_2.re, X_2.im} * s_i(t)
+//   MAC output   Y      : float4 [256 bins][Tcap]        {Y_L.re, Y_L.im, Y_R.re, Y_R.im}
+//   segments     seg    : float  [SR blocks][2 ch][512]  inverse transforms (overlap-add halves)
+//   wet ring     wet    : float  [2 ch][WR samples]      indexed by absolute sample mod WR
+// Bin-major layouts make the partition sum of one bin a contiguous stream that
+// one workgroup owns: no cross-workgroup reduction, coalesced 16-byte lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft512.hip.h"
+
+#define MC_B 256
+#define MC_K 512
+#define MC_NB 256
+#define FWD_TILE 16  // blocks per workgroup of the forward / inverse transform kernels
+
+// Per-block parameters computed on the host in double (Q7 ramp, pans, levels)
+struct BlockParams {
+    double G[4];    // wet gain of path c*2+i attached to this input block: pan_c(panWet_i) level_i e_i(t)
+    float s[2];     // level_i * e_i(t): scale of input i's spectrum in the delay line
+    float pad0[2];
+    float d[4];     // dry gain c*2+i: dry_i pan_c(panDry_i) level_i      (conv.cu:418-427)
+    float pan[4];   // pan_c(panWet_i), c*2+i                              (conv.cu:386-389)
+};
+
+// ---------------------------------------------------------------------------
+// K1: forward transform of T input blocks -> delay-line slots.
+// Replaces f_pack2R2C + memset + cufftExecC2C + f_unpackC22R (conv.cu:35-73,
+// 321-328, 367-371) for one zero-padded 256-frame block per wave pass.  The
+// same kernel prepares IR partitions (conv.cu:207-253): the IR's L/R channels
+// are the two "inputs", slot = partition index, unit scale.
+// grid = ceil(T / 16), block = 256 (4 waves x 4 transforms each).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
+                                             int in_stride,  // floats between successive frames (1, or 2 for interleaved IR)
+                                             int64_t n_frames,  // valid frames in in1/in2 (zero beyond)
+                                             int T, float4* __restrict__ fdl, int ring, int slot0,
+                                             const BlockParams* __restrict__ ptab, int pstride,
+                                             float4* __restrict__ sums,  // [T] raw {S1,S2,A1,A2} or null
+                                             float4* __restrict__ slotpan,  // [ring] or null
+                                             const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[4][FFT_WAVE_LDS];
+    __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
+    load_twiddles(s_tw, g_tw);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb0 = blockIdx.x * FWD_TILE;
+    float2* lds = s_fft[wave];
+    for (int it = 0; it < FWD_TILE / 4; it++) {
+        const int tb = it * 4 + wave;  // block within tile
+        const int t = tb0 + tb;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = make_float2(0.f, 0.f);
+        if (t < T) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {  // n = lane + 64 r < 256: the block; 256..511 stay zero
+                int64_t f = (int64_t)t * MC_B + lane + 64 * r;
+                if (f < n_frames) v[r] = make_float2(in1[f * in_stride], in2[f * in_stride]);
+            }
+        }
+        fft512_wave<-1>(v, lds, s_tw, lane);
+        if (t < T) {
+            float s1 = 1.f, s2 = 1.f;
+            if (ptab) {
+                s1 = ptab[(int64_t)t * pstride].s[0];
+                s2 = ptab[(int64_t)t * pstride].s[1];
+            }
+            // two-for-one split of the packed transform (true spectra; the
+            // reference's DC/Nyquist shortcuts Q1/Q2 are rank-1 terms added in k_post)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int k = lane + 64 * j;
+                float2 za = lds[k], zb = lds[(FFT_N - k) & (FFT_N - 1)];
+                float2 x1, x2;
+                if (k == 0) {
+                    float2 zn = lds[MC_B];
+                    x1 = make_float2(za.x, zn.x);  // {DC, Nyquist} of input 1
+                    x2 = make_float2(za.y, zn.y);  // {DC, Nyquist} of input 2
+                    if (sums) sums[t] = make_float4(za.x, za.y, zn.x, zn.y);  // S1, S2, A1, A2 (unscaled)
+                } else {
+                    x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
+                    x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
+                }
+                s_tile[k][tb] = make_float4(x1.x * s1, x1.y * s1, x2.x * s2, x2.y * s2);
+            }
+            if (slotpan && lane == 0) {
+                const float* pn = ptab[(int64_t)t * pstride].pan;
+                slotpan[(slot0 + t) & (ring - 1)] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+            }
+        }
+        __syncthreads();  // lds reused by the next transform
+    }
+    __syncthreads();
+    // transposed, coalesced store: 16 consecutive slots (256 B) per bin
+    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
+        int tb = idx & (FWD_TILE - 1), k = idx >> 4;
+        int t = tb0 + tb;
+        if (t < T) fdl[(size_t)k * ring + ((slot0 + t) & (ring - 1))] = s_tile[k][tb];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// complex multiply-accumulate helpers.  PACKED handles bin 0, whose float2
+// holds two independent real bins {DC, Nyquist}.
+// (replaces f_pointwiseMultiplyAndScale, conv.cu:102-123, with the true product; Q3)
+// ---------------------------------------------------------------------------
+template <bool PACKED>
+__device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, float xy) {
+    if (PACKED) {
+        acc.x = fmaf(hx, xx, acc.x);
+        acc.y = fmaf(hy, xy, acc.y);
+    } else {
+        acc.x = fmaf(hx, xx, acc.x);
+        acc.x = fmaf(-hy, xy, acc.x);
+        acc.y = fmaf(hx, xy, acc.y);
+        acc.y = fmaf(hy, xx, acc.y);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (batch): partition x bin complex MAC with the IR held on chip.
+// One workgroup = one bin x 256 consecutive output blocks.  Lane j owns output
+// blocks 4j..4j+3; the IR spectra of the bin are wave-uniform and arrive as
+// scalar loads (SGPR operands of the FMAs), the delay-line window of the tile
+// sits in LDS de-interleaved by 4 so that every ds_read_b128 of the sliding
+// window is conflict-free, and each window entry is reused for 4 outputs from
+// registers.  The 4 waves split the partition range; partial sums meet in LDS.
+// grid = 256 bins x ceil(T/256); block ids with equal bin share an XCD (id % 8).
+// ---------------------------------------------------------------------------
+#define MAC_PSEG 1024                       // partitions per LDS window segment
+#define MAC_WQ ((MAC_PSEG + 256 + 8) / 4)   // quarter-window length (entries)
+
+template <bool PACKED>
+__device__ __forceinline__ void mac_sweep(const float4* __restrict__ H0k, const float4* __restrict__ H1k, int pse,
+                                          int q_lo, int q_hi, const float4* s_win, int lane, float2 (&acc)[4][4]) {
+    // window registers: entries 4*lane + q + 0..7
+    float4 w[8];
+    const float4* wbase = s_win + lane + (q_lo >> 2);
+#pragma unroll
+    for (int u = 0; u < 4; u++) w[u] = wbase[u * MAC_WQ];
+    for (int q = q_lo; q < q_hi; q += 4) {
+        const float4* wn = s_win + lane + (q >> 2) + 1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[4 + u] = wn[u * MAC_WQ];
+        const int pb = pse - 4 - q;  // partitions pb..pb+3, step u uses pb+3-u
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float4 h0 = H0k[pb + 3 - u];  // wave-uniform -> scalar loads
+            const float4 h1 = H1k[pb + 3 - u];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 x = w[u + r];
+                cmac<PACKED>(acc[r][0], h0.x, h0.y, x.x, x.y);  // L <- in1 * h_sel0,L
+                cmac<PACKED>(acc[r][1], h1.x, h1.y, x.z, x.w);  // L <- in2 * h_sel1,L
+                cmac<PACKED>(acc[r][2], h0.z, h0.w, x.x, x.y);  // R <- in1 * h_sel0,R
+                cmac<PACKED>(acc[r][3], h1.z, h1.w, x.z, x.w);  // R <- in2 * h_sel1,R
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = w[4 + u];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__ H0, const float4* __restrict__ H1,
+                                                      int pstride_ir,  // slots per bin of the IR arrays
+                                                      int p_begin, int p_end,  // partition range, multiples of 16
+                                                      const float4* __restrict__ fdl, int ring, int slot0, int T,
+                                                      float4 pan,  // pan_c(panWet_i): {L0, L1, R0, R1}
+                                                      float4* __restrict__ Y, int tcap) {
+    __shared__ float4 s_win[4 * MAC_WQ];
+    const int bin = blockIdx.x & (MC_NB - 1);
+    const int tile = blockIdx.x >> 8;
+    const int t0 = tile * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float4* H0k = H0 + (size_t)bin * pstride_ir;
+    const float4* H1k = H1 + (size_t)bin * pstride_ir;
+    const float4* fk = fdl + (size_t)bin * ring;
+
+    float2 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[r][c] = make_float2(0.f, 0.f);
+
+    for (int ps = p_begin; ps < p_end; ps += MAC_PSEG) {
+        const int pse = min(ps + MAC_PSEG, p_end);
+        const int seg = pse - ps;  // multiple of 16
+        // window entry e <-> block (t0 - pse + 1 + e), e in [0, seg + 255]
+        const int nwin = seg + 256;
+        const int sbase = slot0 + t0 - pse + 1;
+        __syncthreads();  // previous segment's readers are done
+        for (int e = threadIdx.x; e < nwin + 4; e += 256) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nwin) x = fk[(sbase + e) & (ring - 1)];
+            s_win[(e & 3) * MAC_WQ + (e >> 2)] = x;
+        }
+        __syncthreads();
+        const int per = seg >> 2;  // partitions per wave, multiple of 4
+        const int q_lo = wave * per, q_hi = q_lo + per;
+        if (bin == 0)
+            mac_sweep<true>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
+        else
+            mac_sweep<false>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
+    }
+    // apply the (batch-uniform) wet pans, then sum the 4 waves' partials in LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(s_win);  // [wave][16][64]
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float2 yl = make_float2(pan.x * acc[r][0].x + pan.y * acc[r][1].x, pan.x * acc[r][0].y + pan.y * acc[r][1].y);
+        float2 yr = make_float2(pan.z * acc[r][2].x + pan.w * acc[r][3].x, pan.z * acc[r][2].y + pan.w * acc[r][3].y);
+        red[(wave * 16 + r * 4 + 0) * 64 + lane] = yl.x;
+        red[(wave * 16 + r * 4 + 1) * 64 + lane] = yl.y;
+        red[(wave * 16 + r * 4 + 2) * 64 + lane] = yr.x;
+        red[(wave * 16 + r * 4 + 3) * 64 + lane] = yr.y;
+    }
+    __syncthreads();
+    {
+        const int o = threadIdx.x;  // output block within the tile: o = 4 j + r
+        const int j = o >> 2, r = o & 3;
+        float f[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) s += red[(w * 16 + r * 4 + c) * 64 + j];
+            f[c] = s;
+        }
+        if (t0 + o < T) Y[(size_t)bin * tcap + t0 + o] = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (stream): the same sum as a bandwidth-bound reduction, for single blocks
+// (the JACK path) and short batches.  Lanes = partitions: each lane loads 16 B
+// of each IR and 16 B of the delay line per partition (coalesced), the pan of
+// the slot's input block is applied per term (exact for time-varying pans).
+// grid = (256 bins, nchunk, T); partial sums per chunk are added by k_inv.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mac_stream(const float4* __restrict__ H0, const float4* __restrict__ H1,
+                                                    int pstride_ir, int p_begin, int p_end, int chunk,
+                                                    const float4* __restrict__ fdl, const float4* __restrict__ slotpan,
+                                                    int ring, int slot0, float4* __restrict__ part, int nchunk) {
+    const int bin = blockIdx.x, ch = blockIdx.y, t = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* H0k = H0 + (size_t)bin * pstride_ir;
+    const float4* H1k = H1 + (size_t)bin * pstride_ir;
+    const float4* fk = fdl + (size_t)bin * ring;
+    const int lo = p_begin + ch * chunk, hi = min(lo + chunk, p_end);
+    const int st = slot0 + t;
+    float2 yl = make_float2(0.f, 0.f), yr = make_float2(0.f, 0.f);
+    const bool packed = (bin == 0);
+    for (int p = lo + (int)threadIdx.x; p < hi; p += 256) {
+        const int slot = (st - p) & (ring - 1);
+        const float4 x = fk[slot];
+        const float4 g = slotpan[slot];
+        const float4 h0 = H0k[p], h1 = H1k[p];
+        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        if (packed) {
+            cmac<true>(a0, h0.x, h0.y, x.x, x.y);
+            cmac<true>(a1, h1.x, h1.y, x.z, x.w);
+            cmac<true>(a2, h0.z, h0.w, x.x, x.y);
+            cmac<true>(a3, h1.z, h1.w, x.z, x.w);
+        } else {
+            cmac<false>(a0, h0.x, h0.y, x.x, x.y);
+            cmac<false>(a1, h1.x, h1.y, x.z, x.w);
+            cmac<false>(a2, h0.z, h0.w, x.x, x.y);
+            cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+        }
+        yl.x += g.x * a0.x + g.y * a1.x;
+        yl.y += g.x * a0.y + g.y * a1.y;
+        yr.x += g.z * a2.x + g.w * a3.x;
+        yr.y += g.z * a2.y + g.w * a3.y;
+    }
+    // wavefront butterfly reduction (64 lanes), then 4 waves through LDS
+    float v[4] = {yl.x, yl.y, yr.x, yr.y};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_xor(v[c], off, 64);
+    }
+    __shared__ float s_red[4][4];
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 o;
+        o.x = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+        o.y = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+        o.z = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
+        o.w = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
+        part[((size_t)t * MC_NB + bin) * nchunk + ch] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: packed inverse transform.  W = Y_L + j Y_R (Hermitian-extended), one
+// 512-point inverse per block, real part = left segment, imaginary = right
+// (replaces the two cufftExecC2C inverse calls, conv.cu:403-408).
+// Y element (bin k, block t) = sum_{c<nsum} Ysrc[k*sk + t*st + c].
+// seg[(seg0 + t) mod sr][ch][512].   grid = ceil(T/16), block = 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int T,
+                                             float* __restrict__ seg, int sr, int seg0,
+                                             const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[4][FFT_WAVE_LDS];
+    __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
+    load_twiddles(s_tw, g_tw);
+    const int tb0 = blockIdx.x * FWD_TILE;
+    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
+        int tb = idx & (FWD_TILE - 1), k = idx >> 4;
+        int t = tb0 + tb;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            const float4* src = Ysrc + (int64_t)k * sk + (int64_t)t * st;
+            for (int c = 0; c < nsum; c++) {
+                float4 a = src[c];
+                y.x += a.x;
+                y.y += a.y;
+                y.z += a.z;
+                y.w += a.w;
+            }
+        }
+        s_tile[k][tb] = y;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2* lds = s_fft[wave];
+    for (int it = 0; it < FWD_TILE / 4; it++) {
+        const int tb = it * 4 + wave;
+        const int t = tb0 + tb;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n = lane + 64 * r;
+            float2 w;
+            if (n == 0) {
+                float4 y = s_tile[0][tb];
+                w = make_float2(y.x, y.z);  // DC of L, R
+            } else if (n == MC_B) {
+                float4 y = s_tile[0][tb];
+                w = make_float2(y.y, y.w);  // Nyquist of L, R
+            } else if (n < MC_B) {
+                float4 y = s_tile[n][tb];
+                w = make_float2(y.x - y.w, y.y + y.z);  // Y_L + j Y_R
+            } else {
+                float4 y = s_tile[FFT_N - n][tb];
+                w = make_float2(y.x + y.w, -y.y + y.z);  // conj(Y_L) + j conj(Y_R)
+            }
+            v[r] = w;
+        }
+        fft512_wave<+1>(v, lds, s_tw, lane);
+        if (t < T) {
+            float* dst = seg + (size_t)((seg0 + t) % sr) * 2 * FFT_N;
+            const float sc = 1.0f / FFT_N;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int n = lane + 64 * j;
+                float2 z = lds[n];
+                dst[n] = z.x * sc;
+                dst[FFT_N + n] = z.y * sc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: overlap-add of the segments into the wet stream (pre-predelay).
+// Output either into the wet ring (absolute sample index mod WR) or into a
+// caller-provided linear buffer [2][T*256] (sharded operation).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T,
+                                             float* __restrict__ wet, int wr, int64_t tau0,  // ring mode
+                                             float* __restrict__ lin) {                         // linear mode (or null)
+    const int t = blockIdx.x, m = threadIdx.x;
+    const float* cur = seg + (size_t)((seg0 + t) % sr) * 2 * FFT_N;
+    const float* prv = seg + (size_t)((seg0 + t + sr - 1) % sr) * 2 * FFT_N;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float v = cur[c * FFT_N + m] + prv[c * FFT_N + MC_B + m];
+        if (lin)
+            lin[(size_t)c * T * MC_B + (size_t)t * MC_B + m] = v;
+        else
+            wet[(size_t)c * wr + ((tau0 + (int64_t)t * MC_B + m) & (wr - 1))] = v;
+    }
+}
+
+// copy a summed linear wet buffer [2][T*256] into the wet ring
+__global__ __launch_bounds__(256) void k_lin2ring(const float* __restrict__ lin, int T, float* __restrict__ wet, int wr,
+                                                  int64_t tau0) {
+    const int t = blockIdx.x, m = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        wet[(size_t)c * wr + ((tau0 + (int64_t)t * MC_B + m) & (wr - 1))] = lin[(size_t)c * T * MC_B + (size_t)t * MC_B + m];
+}
+
+// ---------------------------------------------------------------------------
+// K5: per-block rank-1 terms of the reference's DC / Nyquist quirks (Q1, Q2;
+// conv.cu:61 and :55-71) and their running prefix sums (float64 rings indexed
+// by absolute block).  One workgroup; T <= 256 * 16.
+//   D_L = -(G_L0 S2 sig_0R + G_L1 S2 sig_1L)/N   D_R = -(G_R0 S1 sig_0R + G_R1 S2 sig_1R)/N
+//   Q_c = -(G_c0 A1 alp_0c + G_c1 A2 alp_1c)/N
+// ---------------------------------------------------------------------------
+struct IrSums {
+    double sig[2][2];  // [half][L/R]  sum h
+    double alp[2][2];  // [half][L/R]  sum h (-1)^m
+};
+
+__device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& bp, const IrSums& irs, double inv_n,
+                                           double (&d)[4]) {
+    const double S1 = sa.x, S2 = sa.y, A1 = sa.z, A2 = sa.w;
+    d[0] = -(bp.G[0] * S2 * irs.sig[0][1] + bp.G[1] * S2 * irs.sig[1][0]) * inv_n;
+    d[1] = -(bp.G[2] * S1 * irs.sig[0][1] + bp.G[3] * S2 * irs.sig[1][1]) * inv_n;
+    d[2] = -(bp.G[0] * A1 * irs.alp[0][0] + bp.G[1] * A2 * irs.alp[1][0]) * inv_n;
+    d[3] = -(bp.G[2] * A1 * irs.alp[0][1] + bp.G[3] * A2 * irs.alp[1][1]) * inv_n;
+}
+
+__global__ __launch_bounds__(256) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
+                                              int pstride, int T, IrSums irs, double inv_n, int compat,
+                                              double* __restrict__ cring, int rc, int64_t tabs0) {
+    // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc)
+    __shared__ double s_part[256][4];
+    const int tid = threadIdx.x;
+    const int per = (T + 255) / 256;
+    double run[4] = {0, 0, 0, 0};
+    if (compat) {
+        for (int j = 0; j < per; j++) {
+            const int t = tid * per + j;
+            if (t < T) {
+                double d[4];
+                corr_terms(sums[t], ptab[(int64_t)t * pstride], irs, inv_n, d);
+                for (int c = 0; c < 4; c++) run[c] += d[c];
+            }
+        }
+    }
+    for (int c = 0; c < 4; c++) s_part[tid][c] = run[c];
+    __syncthreads();
+    double base[4] = {0, 0, 0, 0};
+    if (tabs0 > 0) {
+        const double* p = cring + (size_t)((tabs0 - 1) % rc) * 4;
+        for (int c = 0; c < 4; c++) base[c] = p[c];
+    }
+    for (int i = 0; i < tid; i++)
+        for (int c = 0; c < 4; c++) base[c] += s_part[i][c];
+    // second pass: recompute the terms and write the running sums
+    for (int j = 0; j < per; j++) {
+        const int t = tid * per + j;
+        if (t < T) {
+            if (compat) {
+                double d[4];
+                corr_terms(sums[t], ptab[(int64_t)t * pstride], irs, inv_n, d);
+                for (int c = 0; c < 4; c++) base[c] += d[c];
+            }
+            double* o = cring + (size_t)((tabs0 + t) % rc) * 4;
+            for (int c = 0; c < 4; c++) o[c] = base[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: predelay + Q1/Q2 window sums + saturating clamp + dry mix
+// (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
+// conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post(const float* __restrict__ wet, int wr, const double* __restrict__ cring,
+                                              int rc, const BlockParams* __restrict__ ptab, int pstride,
+                                              const float* __restrict__ in1, const float* __restrict__ in2,
+                                              float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
+                                              int64_t predelay, int64_t n_ref, int compat) {
+    const int t = blockIdx.x, m = threadIdx.x;
+    const int64_t i = (int64_t)t * MC_B + m;
+    const int64_t tau = tabs0 * MC_B + i;
+    const int64_t u = tau - predelay;
+    float wl = 0.f, wr_ = 0.f;
+    if (u >= 0) {
+        wl = wet[(size_t)(u & (wr - 1))];
+        wr_ = wet[(size_t)wr + (u & (wr - 1))];
+    }
+    double cl = 0.0, cr = 0.0;
+    if (compat && u >= 0) {
+        // input blocks t' with predelay <= tau - 256 t' < n_ref (shift by predelay, cut at n_ref: Q8)
+        const int64_t thi = u >> 8;
+        const int64_t v = tau - n_ref;
+        const int64_t tlo = v >= 0 ? (v >> 8) : -1;
+        const double* a = cring + (size_t)(thi % rc) * 4;
+        double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
+        if (tlo >= 0) {
+            const double* b = cring + (size_t)(tlo % rc) * 4;
+            d0 -= b[0];
+            d1 -= b[1];
+            q0 -= b[2];
+            q1 -= b[3];
+        }
+        const double sg = (u & 1) ? -1.0 : 1.0;
+        cl = d0 + sg * q0;
+        cr = d1 + sg * q1;
+    }
+    const BlockParams& bp = ptab[(int64_t)t * pstride];
+    const float x1 = in1[i], x2 = in2[i];
+    float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
+    float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
+    outL[i] = vl + x1 * bp.d[0] + x2 * bp.d[1];
+    outR[i] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+}

@@ -1,0 +1,736 @@
+// mcconv.hip — engine state + the C ABI of include/mcconv.h.
+//
+// One mc_engine corresponds to one reference `Convolution` object
+// (conv.h:30-86): it owns the IR bank (_irBuffers, conv.h:77), the
+// frequency-domain delay line that replaces the reference's whole-IR spectra
+// and N-long overlap-add accumulator (conv.h:72-75), the per-half parameters
+// (cc[2].value, conv.h:33-50) and the running-mean timer (conv.h:61,79-80).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/mcconv.h"
+#include "kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(MC_ERR_HIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kMaxIrs = 256;
+constexpr int kStageBufs = 4;
+constexpr int kEvPool = 1024;
+
+inline uint32_t next_pow2(uint64_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline double pan_l(double p) { return p >= 0 ? 1 - p : 1; }  // conv.cu:386
+inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
+
+struct IrEntry {
+    float4* d_H = nullptr;
+    uint64_t taps = 0;
+    int P = 0;
+    double sums[4] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct mc_engine {
+    mc_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 8, Tstream = 0;
+    int stream_threshold = 0;
+    IrEntry irs[kMaxIrs];
+    int nirs = 0;
+
+    float4 *d_fdl = nullptr, *d_slotpan = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
+    float *d_seg = nullptr, *d_wet = nullptr, *d_lin = nullptr;
+    double* d_cring = nullptr;
+    BlockParams* d_ptab = nullptr;
+    float2* d_tw = nullptr;
+    float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // in1, in2, outL, outR staging for host-pointer calls
+    float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Tmax * 256
+    BlockParams* h_ptab[kStageBufs] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ptab_ev[kStageBufs];
+    bool ptab_ev_used[kStageBufs] = {false, false, false, false};
+    int ptab_next = 0;
+
+    // parameters: written by any thread, sampled at the start of a process call
+    std::mutex pmu;
+    mc_cc_value cc[2];
+
+    // signal state
+    double e[2] = {0, 0};  // cross-fade coefficient of each half's selected IR (Q7)
+    uint64_t t_abs = 0;    // blocks processed
+    bool uniform_valid = false;
+    BlockParams uniform_bp;
+    int cur_pstride = 1;
+    uint64_t cur_predelay = 0;
+    IrSums cur_irsums;
+    bool partial_pending = false;
+
+    // avgRuntime (conv.cu:454-462): first 10 calls discarded
+    double runtime_ms = 0;
+    int nruns = -10;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // kernel timing
+    bool ktiming = false;
+    hipEvent_t kev[kEvPool][2];
+    uint32_t kev_blocks[kEvPool];
+    int kev_n = 0;
+    bool kev_created = false;
+    mc_kernel_stats ks;
+};
+
+namespace {
+
+void host_twiddles(std::vector<float2>& tw) {
+    tw.resize(FFT_N);
+    for (int m = 0; m < FFT_N; m++) {
+        double a = -2.0 * M_PI * (double)m / (double)FFT_N;
+        tw[m] = make_float2((float)cos(a), (float)sin(a));
+    }
+}
+
+int drain_kernel_events(mc_engine* e) {
+    if (!e->kev_n) return MC_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->kev_n; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->kev[i][0], e->kev[i][1]));
+        e->ks.launches++;
+        e->ks.blocks += e->kev_blocks[i];
+        e->ks.total_ms += ms;
+        e->ks.last_ms = ms;
+    }
+    e->kev_n = 0;
+    return MC_OK;
+}
+
+int zero_state(mc_engine* e) {
+    HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_slotpan, 0, sizeof(float4) * (size_t)e->ring, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_wet, 0, sizeof(float) * 2 * (size_t)e->wr, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_cring, 0, sizeof(double) * 4 * (size_t)e->rc, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->e[0] = e->e[1] = 0.0;
+    e->t_abs = 0;
+    e->uniform_valid = false;
+    e->partial_pending = false;
+    return MC_OK;
+}
+
+// Build the per-block parameter table for T blocks starting now (host, double).
+// Advances the cross-fade coefficients exactly like f_interpolate + vsteps--
+// (conv.cu:27, 339-353).  Returns pstride (0 = one entry serves all blocks).
+int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_tab, int* out_n) {
+    BlockParams* tab = e->h_ptab[e->ptab_next];
+    bool all_same = true;
+    for (int t = 0; t < T; t++) {
+        BlockParams& bp = tab[t];
+        for (int i = 0; i < 2; i++) {
+            double wet = (double)cc[i].wet;
+            e->e[i] += (wet - e->e[i]) / (double)(cc[i].vsteps + 5);
+            if (std::fabs(wet - e->e[i]) <= 1e-300 + 4e-16 * std::fabs(wet)) e->e[i] = wet;
+            if (cc[i].vsteps > 0) cc[i].vsteps--;
+        }
+        for (int i = 0; i < 2; i++) {
+            const double lvl = (double)cc[i].level;
+            const double pl = pan_l((double)cc[i].panWet), pr = pan_r((double)cc[i].panWet);
+            bp.s[i] = (float)(lvl * e->e[i]);
+            // G uses the float-rounded delay-line scale so that the Q1/Q2 terms
+            // match what the MAC actually accumulates
+            bp.G[0 * 2 + i] = pl * lvl * e->e[i];
+            bp.G[1 * 2 + i] = pr * lvl * e->e[i];
+            bp.pan[0 * 2 + i] = (float)pl;
+            bp.pan[1 * 2 + i] = (float)pr;
+            bp.d[0 * 2 + i] = (float)((double)cc[i].dry * pan_l((double)cc[i].panDry) * lvl);
+            bp.d[1 * 2 + i] = (float)((double)cc[i].dry * pan_r((double)cc[i].panDry) * lvl);
+        }
+        bp.pad0[0] = bp.pad0[1] = 0.f;
+        if (t > 0 && std::memcmp(&tab[t], &tab[0], sizeof(BlockParams)) != 0) all_same = false;
+    }
+    *out_tab = tab;
+    *out_n = all_same ? 1 : T;
+    return all_same ? 0 : 1;
+}
+
+struct BatchCtx {
+    int T;
+    int slot0, seg0;
+    int64_t tau0;
+};
+
+// forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial
+int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin) {
+    if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
+    mc_cc_value cc[2];
+    {
+        std::lock_guard<std::mutex> lk(e->pmu);
+        cc[0] = e->cc[0];
+        cc[1] = e->cc[1];
+    }
+    for (int i = 0; i < 2; i++) {
+        if (cc[i].select >= (uint64_t)kMaxIrs || !e->irs[cc[i].select].d_H)
+            return fail(MC_ERR_STATE, "half %d selects IR %llu which is not loaded", i, (unsigned long long)cc[i].select);
+    }
+    if (cc[0].predelay > MC_MAX_PREDELAY) return fail(MC_ERR_ARG, "predelay %llu > %d", (unsigned long long)cc[0].predelay, MC_MAX_PREDELAY);
+    const IrEntry& ir0 = e->irs[cc[0].select];
+    const IrEntry& ir1 = e->irs[cc[1].select];
+
+    // per-block parameter table
+    BlockParams* tab;
+    int ntab;
+    // reuse of a pinned staging buffer: wait until its previous upload has run
+    if (e->ptab_ev_used[e->ptab_next]) HIP_TRY(hipEventSynchronize(e->ptab_ev[e->ptab_next]));
+    int pstride = build_params(e, T, cc, &tab, &ntab);
+    {
+        // vsteps counts down on the engine's copy too (conv.cu:345,353)
+        std::lock_guard<std::mutex> lk(e->pmu);
+        for (int i = 0; i < 2; i++) {
+            uint64_t used = std::min<uint64_t>(e->cc[i].vsteps, (uint64_t)T);
+            e->cc[i].vsteps -= used;
+        }
+    }
+    bool need_upload = true;
+    if (pstride == 0 && e->uniform_valid && std::memcmp(&e->uniform_bp, &tab[0], sizeof(BlockParams)) == 0) need_upload = false;
+    if (need_upload) {
+        HIP_TRY(hipMemcpyAsync(e->d_ptab, tab, sizeof(BlockParams) * (size_t)ntab, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->ptab_ev[e->ptab_next], e->stream));
+        e->ptab_ev_used[e->ptab_next] = true;
+        e->ptab_next = (e->ptab_next + 1) % kStageBufs;
+        e->uniform_valid = (pstride == 0);
+        if (pstride == 0) e->uniform_bp = tab[0];
+    }
+    e->cur_pstride = pstride;
+    e->cur_predelay = cc[0].predelay;
+    for (int c = 0; c < 2; c++) {
+        e->cur_irsums.sig[0][c] = ir0.sums[c];
+        e->cur_irsums.sig[1][c] = ir1.sums[c];
+        e->cur_irsums.alp[0][c] = ir0.sums[2 + c];
+        e->cur_irsums.alp[1][c] = ir1.sums[2 + c];
+    }
+
+    const int slot0 = (int)(e->t_abs & (uint64_t)(e->ring - 1));
+    const int seg0 = (int)(e->t_abs % (uint64_t)e->sr);
+    const int64_t tau0 = (int64_t)e->t_abs * MC_B;
+
+    // K1
+    hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
+                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, e->d_ptab, pstride, e->d_sums, e->d_slotpan, e->d_tw);
+
+    // partition range of this engine (shard), multiples of 16
+    int p_hi = round_up(std::max(ir0.P, ir1.P), 16);
+    int p_begin = (int)e->cfg.part_begin, p_end = e->cfg.part_end ? std::min<int>((int)e->cfg.part_end, p_hi) : p_hi;
+    if (p_begin > p_end) p_begin = p_end;
+    const bool resident = T >= e->stream_threshold;
+    const bool empty = (p_end == p_begin);
+
+    hipEvent_t *k0 = nullptr, *k1 = nullptr;
+    if (e->ktiming) {
+        if (e->kev_n == kEvPool) {
+            int rc = drain_kernel_events(e);
+            if (rc) return rc;
+        }
+        k0 = &e->kev[e->kev_n][0];
+        k1 = &e->kev[e->kev_n][1];
+        e->kev_blocks[e->kev_n] = (uint32_t)T;
+        HIP_TRY(hipEventRecord(*k0, e->stream));
+    }
+    int64_t sk, st;
+    int nsum;
+    const float4* ysrc;
+    if (resident) {
+        const float4 pan = make_float4(tab[0].pan[0], tab[0].pan[1], tab[0].pan[2], tab[0].pan[3]);
+        if (empty) {
+            HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * e->Tmax, e->stream));
+        } else {
+            hipLaunchKernelGGL(k_mac_resident, dim3(MC_NB * ((T + 255) / 256)), dim3(256), 0, e->stream, ir0.d_H, ir1.d_H,
+                               e->Pstride, p_begin, p_end, e->d_fdl, e->ring, slot0, T, pan, e->d_Y, e->Tmax);
+        }
+        ysrc = e->d_Y;
+        sk = e->Tmax;
+        st = 1;
+        nsum = 1;
+    } else {
+        int span = p_end - p_begin;
+        int chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
+        if (empty) {
+            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)T * MC_NB * e->nchunk, e->stream));
+        } else {
+            hipLaunchKernelGGL(k_mac_stream, dim3(MC_NB, e->nchunk, T), dim3(256), 0, e->stream, ir0.d_H, ir1.d_H, e->Pstride,
+                               p_begin, p_end, chunk, e->d_fdl, e->d_slotpan, e->ring, slot0, e->d_part, e->nchunk);
+        }
+        ysrc = e->d_part;
+        sk = e->nchunk;
+        st = (int64_t)MC_NB * e->nchunk;
+        nsum = e->nchunk;
+    }
+    if (e->ktiming) {
+        HIP_TRY(hipEventRecord(*k1, e->stream));
+        e->kev_n++;
+        e->ks.resident = resident ? 1 : 0;
+        e->ks.partitions = (uint32_t)(p_end - p_begin);
+    }
+
+    // K3, K4
+    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, st, nsum, T, e->d_seg,
+                       e->sr, seg0, e->d_tw);
+    hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, e->d_wet, e->wr, tau0, lin);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// Q1/Q2 prefix sums, predelay, clamp, dry mix; advances the block counter
+int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* lin_sum, float* d_outL, float* d_outR, int T) {
+    const int64_t tau0 = (int64_t)e->t_abs * MC_B;
+    if (lin_sum) hipLaunchKernelGGL(k_lin2ring, dim3(T), dim3(256), 0, e->stream, lin_sum, T, e->d_wet, e->wr, tau0);
+    hipLaunchKernelGGL(k_corr, dim3(1), dim3(256), 0, e->stream, e->d_sums, e->d_ptab, e->cur_pstride, T, e->cur_irsums,
+                       1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)e->t_abs);
+    hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_wet, e->wr, e->d_cring, e->rc, e->d_ptab, e->cur_pstride,
+                       d_in1, d_in2, d_outL, d_outR, T, (int64_t)e->t_abs, (int64_t)e->cur_predelay, (int64_t)e->cfg.n_ref,
+                       (int)e->cfg.compat);
+    HIP_TRY(hipGetLastError());
+    e->t_abs += (uint64_t)T;
+    return MC_OK;
+}
+
+int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
+    if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
+    if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
+    const size_t n = (size_t)T * MC_B, bytes = n * sizeof(float);
+    const size_t cap = (size_t)e->Tmax * MC_B;
+    std::memcpy(e->h_io + 0 * cap, in1, bytes);
+    std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_io[1], e->h_io + 1 * cap, bytes, hipMemcpyHostToDevice, e->stream));
+    int rc = run_front(e, e->d_io[0], e->d_io[1], T, nullptr);
+    if (rc) return rc;
+    rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], T);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_io + 2 * cap, e->d_io[2], bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_io + 3 * cap, e->d_io[3], bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::memcpy(outL, e->h_io + 2 * cap, bytes);
+    std::memcpy(outR, e->h_io + 3 * cap, bytes);
+    return MC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mc_abi_version(void) { return MC_ABI_VERSION; }
+const char* mc_last_error(void) { return g_err; }
+
+void mc_default_config(mc_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(mc_config);
+    cfg->device = -1;
+    cfg->n_ref = 512 * 256;  // CONV_DEFAULT_FFTSIZE, conv.h:10-12
+    cfg->max_batch = 256;
+    cfg->compat = 1;
+}
+
+void mc_default_params(mc_cc_value* v) {
+    if (!v) return;
+    v->select = 0;  // conv.h:40-48
+    v->predelay = 0;
+    v->speed = 100;
+    v->vsteps = 0;
+    v->dry = 0.5f;
+    v->wet = 0.5f;
+    v->panDry = 0.0f;
+    v->panWet = 0.0f;
+    v->level = 1.0f;
+}
+
+int mc_create(const mc_config* cfg, mc_engine** out) {
+    if (!cfg || !out) return fail(MC_ERR_ARG, "null argument");
+    if (cfg->struct_size != sizeof(mc_config)) return fail(MC_ERR_ARG, "mc_config size mismatch (%u vs %zu)", cfg->struct_size, sizeof(mc_config));
+    if (cfg->n_ref < 4096 || (cfg->n_ref & (cfg->n_ref - 1))) return fail(MC_ERR_ARG, "n_ref must be a power of two >= 4096");
+    if (cfg->n_ref > (1ull << 26)) return fail(MC_ERR_ARG, "n_ref too large");
+    if (cfg->max_batch < 1 || cfg->max_batch > 4096) return fail(MC_ERR_ARG, "max_batch must be in [1, 4096]");
+    if ((cfg->part_begin % 16) || (cfg->part_end % 16)) return fail(MC_ERR_ARG, "partition shard bounds must be multiples of 16");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(MC_ERR_HIP, "no HIP device");
+    int dev = cfg->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(MC_ERR_ARG, "device %d out of range (%d devices)", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+
+    mc_engine* e = new (std::nothrow) mc_engine();
+    if (!e) return fail(MC_ERR_NOMEM, "out of host memory");
+    e->cfg = *cfg;
+    e->device = dev;
+    mc_default_params(&e->cc[0]);
+    mc_default_params(&e->cc[1]);
+    std::memset(&e->ks, 0, sizeof(e->ks));
+    e->Tmax = (int)cfg->max_batch;
+    e->Pcap = cfg->max_partitions ? (int)cfg->max_partitions : (int)((cfg->n_ref - 1024 + MC_B - 1) / MC_B);
+    e->Pstride = (int)next_pow2((uint64_t)round_up(e->Pcap, 16));
+    e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tmax + 16);
+    e->sr = e->Tmax + 2;
+    e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
+    e->rc = (int)(cfg->n_ref / MC_B) + e->Tmax + 64;
+    e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 32;
+    e->Tstream = std::min(e->Tmax, std::max(1, e->stream_threshold - 1));
+
+#define ENG_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            int _rc = fail(MC_ERR_HIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            mc_destroy(e);                                                                                \
+            return _rc;                                                                                   \
+        }                                                                                                 \
+    } while (0)
+
+    ENG_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
+    ENG_TRY(hipMalloc(&e->d_slotpan, sizeof(float4) * (size_t)e->ring));
+    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk));
+    ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
+    ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
+    ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
+    ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
+    for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
+    ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Tmax * MC_B, hipHostMallocDefault));
+    for (int i = 0; i < kStageBufs; i++) {
+        ENG_TRY(hipHostMalloc(&e->h_ptab[i], sizeof(BlockParams) * (size_t)e->Tmax, hipHostMallocDefault));
+        ENG_TRY(hipEventCreateWithFlags(&e->ptab_ev[i], hipEventDisableTiming));
+    }
+    ENG_TRY(hipEventCreate(&e->ev0));
+    ENG_TRY(hipEventCreate(&e->ev1));
+    {
+        std::vector<float2> tw;
+        host_twiddles(tw);
+        ENG_TRY(hipMemcpy(e->d_tw, tw.data(), sizeof(float2) * FFT_N, hipMemcpyHostToDevice));
+    }
+    {
+        int rc = zero_state(e);
+        if (rc) {
+            mc_destroy(e);
+            return rc;
+        }
+    }
+#undef ENG_TRY
+    *out = e;
+    return MC_OK;
+}
+
+void mc_destroy(mc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (int i = 0; i < kMaxIrs; i++)
+        if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
+    (void)hipFree(e->d_fdl);
+    (void)hipFree(e->d_slotpan);
+    (void)hipFree(e->d_Y);
+    (void)hipFree(e->d_part);
+    (void)hipFree(e->d_sums);
+    (void)hipFree(e->d_seg);
+    (void)hipFree(e->d_wet);
+    (void)hipFree(e->d_cring);
+    (void)hipFree(e->d_ptab);
+    (void)hipFree(e->d_tw);
+    for (int i = 0; i < 4; i++) (void)hipFree(e->d_io[i]);
+    if (e->h_io) (void)hipHostFree(e->h_io);
+    for (int i = 0; i < kStageBufs; i++) {
+        if (e->h_ptab[i]) {
+            (void)hipHostFree(e->h_ptab[i]);
+            (void)hipEventDestroy(e->ptab_ev[i]);
+        }
+    }
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->kev_created)
+        for (int i = 0; i < kEvPool; i++) {
+            (void)hipEventDestroy(e->kev[i][0]);
+            (void)hipEventDestroy(e->kev[i][1]);
+        }
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int mc_reset(mc_engine* e) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    return zero_state(e);
+}
+
+int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uint64_t nframes) {
+    // Convolution::prepare, conv.cu:207-253
+    if (!e || !lr) return fail(MC_ERR_ARG, "null argument");
+    if (idx >= (uint64_t)kMaxIrs) return fail(MC_ERR_ARG, "IR index %llu >= %d", (unsigned long long)idx, kMaxIrs);
+    if (nframes >= e->cfg.n_ref) return fail(MC_ERR_ARG, "nframes >= n_ref");
+    if (frames == 0) return fail(MC_ERR_ARG, "empty IR");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t n = std::min<uint64_t>(frames, e->cfg.n_ref - nframes);  // conv.cu:239
+    const int P = (int)((n + MC_B - 1) / MC_B);
+    if (P > e->Pcap) return fail(MC_ERR_ARG, "IR needs %d partitions, engine capacity is %d", P, e->Pcap);
+    IrEntry& ir = e->irs[idx];
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!ir.d_H) HIP_TRY(hipMalloc(&ir.d_H, sizeof(float4) * (size_t)MC_NB * e->Pstride));
+    float* d_lr = nullptr;
+    HIP_TRY(hipMalloc(&d_lr, sizeof(float) * 2 * n));
+    hipError_t er = hipMemcpy(d_lr, lr, sizeof(float) * 2 * n, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemsetAsync(ir.d_H, 0, sizeof(float4) * (size_t)MC_NB * e->Pstride, e->stream);
+    if (er == hipSuccess) {
+        hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
+                           ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw);
+        er = hipGetLastError();
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_lr);
+    if (er != hipSuccess) return fail(MC_ERR_HIP, "IR preparation failed: %s", hipGetErrorString(er));
+    double s[4] = {0, 0, 0, 0};
+    for (uint64_t m = 0; m < n; m++) {
+        const double sg = (m & 1) ? -1.0 : 1.0;
+        s[0] += lr[2 * m];
+        s[1] += lr[2 * m + 1];
+        s[2] += sg * lr[2 * m];
+        s[3] += sg * lr[2 * m + 1];
+    }
+    std::memcpy(ir.sums, s, sizeof(s));
+    ir.taps = n;
+    ir.P = P;
+    if ((int)idx + 1 > e->nirs) e->nirs = (int)idx + 1;
+    e->uniform_valid = false;
+    return MC_OK;
+}
+
+int mc_num_irs(const mc_engine* e) { return e ? e->nirs : 0; }
+
+int mc_ir_info(const mc_engine* e, uint64_t idx, double out[6]) {
+    if (!e || !out || idx >= (uint64_t)kMaxIrs || !e->irs[idx].d_H) return fail(MC_ERR_ARG, "IR %llu not loaded", (unsigned long long)idx);
+    for (int i = 0; i < 4; i++) out[i] = e->irs[idx].sums[i];
+    out[4] = (double)e->irs[idx].taps;
+    out[5] = (double)e->irs[idx].P;
+    return MC_OK;
+}
+
+int mc_set_params(mc_engine* e, int half, const mc_cc_value* v) {
+    if (!e || !v || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(e->pmu);
+    e->cc[half] = *v;
+    return MC_OK;
+}
+
+int mc_get_params(const mc_engine* e, int half, mc_cc_value* v) {
+    if (!e || !v || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
+    mc_engine* m = const_cast<mc_engine*>(e);
+    std::lock_guard<std::mutex> lk(m->pmu);
+    *v = m->cc[half];
+    return MC_OK;
+}
+
+int mc_handle_cc(mc_engine* e, int half, const uint8_t ccmap[8], uint8_t m2, int val) {
+    // handleCC, conv.cu:255-276
+    if (!e || !ccmap || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(e->pmu);
+    mc_cc_value& v = e->cc[half];
+    const uint64_t nb = (uint64_t)e->nirs;
+    if (ccmap[0] == m2) {
+        v.select = (uint64_t)val * nb / 0x80;
+        v.vsteps = v.speed;
+    }
+    if (ccmap[1] == m2) v.predelay = (uint64_t)val * MC_MAX_PREDELAY / 0x80;
+    if (ccmap[2] == m2) v.dry = val / 128.0f;
+    if (ccmap[3] == m2) v.wet = val / 128.0f;
+    if (ccmap[5] == m2) v.panDry = val / 64.0f - 1;
+    if (ccmap[6] == m2) v.panWet = val / 64.0f - 1;
+    if (ccmap[7] == m2) v.level = val / 128.0f;
+    if (ccmap[4] == m2) {
+        v.speed = ((uint64_t)val * MC_MAX_SPEED) / 0x80;
+        if (v.vsteps > v.speed) v.vsteps = v.speed;
+    }
+    return MC_OK;
+}
+
+int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, uint64_t nframes) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    if (nframes != MC_BLOCK) return fail(MC_ERR_ARG, "nframes must be %d (got %llu)", MC_BLOCK, (unsigned long long)nframes);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    int rc = process_host(e, in1, in2, outL, outR, 1);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (++e->nruns > 0) e->runtime_ms += ms;  // conv.cu:462
+    return MC_OK;
+}
+
+int mc_process_batch(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, uint64_t nblocks) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    return process_host(e, in1, in2, outL, outR, (int)std::min<uint64_t>(nblocks, 1u << 30));
+}
+
+int mc_process_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, float* d_outL, float* d_outR, uint64_t nblocks) {
+    if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    int rc = run_front(e, d_in1, d_in2, T, nullptr);
+    if (rc) return rc;
+    return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
+}
+
+int mc_partial_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, float* d_partial, uint64_t nblocks) {
+    if (!e || !d_in1 || !d_in2 || !d_partial) return fail(MC_ERR_ARG, "null argument");
+    if (e->partial_pending) return fail(MC_ERR_STATE, "previous partial batch not finished");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    int rc = run_front(e, d_in1, d_in2, T, d_partial);
+    if (rc) return rc;
+    e->partial_pending = true;
+    return MC_OK;
+}
+
+int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, const float* d_wet_sum, float* d_outL,
+                           float* d_outR, uint64_t nblocks) {
+    if (!e || !d_in1 || !d_in2 || !d_wet_sum || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
+    if (!e->partial_pending) return fail(MC_ERR_STATE, "no partial batch pending");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks outside range");
+    e->partial_pending = false;
+    return run_back(e, d_in1, d_in2, d_wet_sum, d_outL, d_outR, T);
+}
+
+int mc_sync(mc_engine* e) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return MC_OK;
+}
+
+int mc_set_stream(mc_engine* e, void* s) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stream = s ? (hipStream_t)s : e->own_stream;
+    return MC_OK;
+}
+
+void* mc_get_stream(mc_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+double mc_avg_runtime_ms(const mc_engine* e) { return (e && e->nruns > 0) ? e->runtime_ms / e->nruns : 0.0; }  // conv.h:61
+
+int mc_enable_kernel_timing(mc_engine* e, int on) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    if (on && !e->kev_created) {
+        for (int i = 0; i < kEvPool; i++) {
+            HIP_TRY(hipEventCreate(&e->kev[i][0]));
+            HIP_TRY(hipEventCreate(&e->kev[i][1]));
+        }
+        e->kev_created = true;
+    }
+    if (!on) {
+        int rc = drain_kernel_events(e);
+        if (rc) return rc;
+    }
+    e->ktiming = on != 0;
+    return MC_OK;
+}
+
+int mc_get_kernel_stats(mc_engine* e, mc_kernel_stats* out, int reset) {
+    if (!e || !out) return fail(MC_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = drain_kernel_events(e);
+    if (rc) return rc;
+    *out = e->ks;
+    if (reset) {
+        uint32_t res = e->ks.resident, parts = e->ks.partitions;
+        std::memset(&e->ks, 0, sizeof(e->ks));
+        e->ks.resident = res;
+        e->ks.partitions = parts;
+    }
+    return MC_OK;
+}
+
+uint64_t mc_algorithmic_bytes_per_block(const mc_engine* e) {
+    // 4 IR paths + 2 delay-line inputs, P partitions, 256 bins x 8 B
+    if (!e) return 0;
+    mc_engine* m = const_cast<mc_engine*>(e);
+    std::lock_guard<std::mutex> lk(m->pmu);
+    const IrEntry& a = e->irs[e->cc[0].select % kMaxIrs];
+    const IrEntry& b = e->irs[e->cc[1].select % kMaxIrs];
+    int P = std::max(a.P, b.P);
+    if (e->cfg.part_end) P = std::max(0, std::min<int>(P, (int)e->cfg.part_end) - (int)e->cfg.part_begin);
+    return (uint64_t)(4 + 2) * (uint64_t)P * MC_NB * 8ull;
+}
+
+uint64_t mc_blocks_processed(const mc_engine* e) { return e ? e->t_abs : 0; }
+
+int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off, uint64_t bytes, uint64_t dims[4]) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    if (dims) {
+        dims[0] = (uint64_t)e->Pstride;
+        dims[1] = (uint64_t)e->ring;
+        dims[2] = (uint64_t)e->Tmax;
+        dims[3] = (uint64_t)e->wr;
+    }
+    if (!dst || !bytes) return MC_OK;
+    const char* src = nullptr;
+    uint64_t cap = 0;
+    switch (which) {
+        case 0:
+            if (idx >= (uint64_t)kMaxIrs || !e->irs[idx].d_H) return fail(MC_ERR_ARG, "IR not loaded");
+            src = (const char*)e->irs[idx].d_H;
+            cap = sizeof(float4) * (uint64_t)MC_NB * e->Pstride;
+            break;
+        case 1: src = (const char*)e->d_fdl; cap = sizeof(float4) * (uint64_t)MC_NB * e->ring; break;
+        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * e->Tmax; break;
+        case 3: src = (const char*)e->d_seg; cap = sizeof(float) * (uint64_t)e->sr * 2 * FFT_N; break;
+        case 4: src = (const char*)e->d_wet; cap = sizeof(float) * 2 * (uint64_t)e->wr; break;
+        case 5: src = (const char*)e->d_cring; cap = sizeof(double) * 4 * (uint64_t)e->rc; break;
+        default: return fail(MC_ERR_ARG, "unknown buffer %d", which);
+    }
+    if (off + bytes > cap) return fail(MC_ERR_ARG, "read beyond buffer (%llu + %llu > %llu)", (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)cap);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(dst, src + off, bytes, hipMemcpyDeviceToHost));
+    return MC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+/*
+ * mcconv.h — C ABI of the MI355X partitioned-convolution reverb engine
+ * (libmcconv.so, hand-written HIP for gfx950).
+ *
+ * This is the drop-in boundary for the reference's hot path: the entry points
+ * are what a binding for limitz/cuda-audio's `Convolution` class needs, one
+ * per reference interface (citations are file:line under the reference's src/):
+ *
+ *   mc_create            <- Convolution::Convolution(name, fftSize)   conv.h:52, conv.cu:142-195
+ *   mc_destroy           <- (reference never frees; conv.h:53-54)
+ *   mc_load_ir           <- Convolution::prepare(idx, wav, nframes)    conv.h:63, conv.cu:207-253
+ *   mc_set_params /
+ *   mc_get_params        <- public Convolution::cc[2].value            conv.h:33-50 (written by main.cu:49-70)
+ *   mc_handle_cc         <- Convolution::onMidiMessage / handleCC      conv.h:65, conv.cu:255-285
+ *   mc_process           <- Convolution::onProcess(nframes)            conv.h:59, conv.cu:287-466
+ *   mc_avg_runtime_ms    <- Convolution::avgRuntime()                  conv.h:61, conv.cu:454-462
+ *   mc_process_batch*    <- the same per-block path run over T consecutive
+ *                           blocks in one call (throughput mode; new)
+ *   mc_partial_* / mc_finish_* <- the two halves of a batch around the
+ *                           cross-GPU sum when IR partitions are sharded (new)
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Every function
+ * returns 0 on success or a negative mc_status, never throws, and leaves a
+ * message for mc_last_error() (thread-local).  The caller keeps ownership of
+ * every pointer it passes; the engine owns all device memory.
+ *
+ * Threading (mirrors SURVEY.md §8b): mc_process* is single-caller per engine;
+ * mc_set_params / mc_handle_cc may be called from another thread (values are
+ * sampled once at the start of each process call); mc_load_ir must not run
+ * concurrently with mc_process*.
+ */
+#ifndef MCCONV_H
+#define MCCONV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+#define MC_BLOCK 256          /* frames per block (JACK period the engine is built for) */
+#define MC_MAX_PREDELAY 8192  /* conv.h:26-28 */
+#define MC_MAX_SPEED 1024     /* conv.h:22-24 */
+
+typedef enum {
+    MC_OK = 0,
+    MC_ERR_ARG = -1,      /* bad argument / unsupported size */
+    MC_ERR_HIP = -2,      /* HIP runtime error (message has the call) */
+    MC_ERR_STATE = -3,    /* call not valid in this state (e.g. no IR loaded) */
+    MC_ERR_NOMEM = -4
+} mc_status;
+
+typedef struct mc_engine mc_engine;
+
+typedef struct {
+    uint32_t struct_size;   /* sizeof(mc_config), for ABI evolution */
+    int32_t device;         /* HIP device ordinal; -1 = current device */
+    uint64_t n_ref;         /* the reference's fftSize (conv.h:52): IR truncation n_ref-1024
+                               (conv.cu:239), Q1/Q2 window and 1/n_ref factors */
+    uint32_t max_batch;     /* largest nblocks accepted by the batch calls (>=1) */
+    uint32_t max_partitions;/* 0 = derive from n_ref: ceil((n_ref-1024)/256) */
+    uint32_t compat;        /* 1 = bug-compatible with conv.cu (DC/Nyquist terms Q1/Q2);
+                               0 = plain linear convolution */
+    uint32_t part_begin;    /* IR-partition shard [part_begin, part_end) computed by this */
+    uint32_t part_end;      /* engine; 0,0 = all partitions (single GPU) */
+    uint32_t stream_threshold; /* batches shorter than this use the streaming MAC kernel
+                               (0 = default) */
+    uint32_t reserved[5];
+} mc_config;
+
+/* mirrors Convolution::CC::value (conv.h:38-49); same defaults via mc_default_params */
+typedef struct {
+    uint64_t select;    /* index of the loaded IR used by this half */
+    uint64_t predelay;  /* samples, [0, 8192]; half 0's value is used for both channels (conv.cu:412,415) */
+    uint64_t speed;     /* cross-fade length in blocks, [0, 1024] */
+    uint64_t vsteps;    /* remaining cross-fade steps (set to speed by a select CC) */
+    float dry, wet, panDry, panWet, level;
+} mc_cc_value;
+
+typedef struct {
+    uint64_t launches;      /* MAC-kernel launches timed so far */
+    uint64_t blocks;        /* blocks those launches processed */
+    double total_ms;        /* sum of HIP-event durations of those launches */
+    double last_ms;
+    uint32_t resident;      /* 1 = the last launch used the resident (batch) kernel */
+    uint32_t partitions;    /* partitions swept per block by the last launch */
+} mc_kernel_stats;
+
+uint32_t mc_abi_version(void);
+const char *mc_last_error(void);
+void mc_default_config(mc_config *cfg);
+void mc_default_params(mc_cc_value *v);
+
+int mc_create(const mc_config *cfg, mc_engine **out);
+void mc_destroy(mc_engine *e);
+int mc_reset(mc_engine *e); /* zero all signal state (delay line, tails, cross-fade) */
+
+/* lr: interleaved L,R float frames as WavFile holds them (already scaled, wav.cu Q5);
+ * nframes: the reference's third prepare() argument (1024). Host pointer. */
+int mc_load_ir(mc_engine *e, uint64_t idx, const float *lr, uint64_t frames, uint64_t nframes);
+int mc_num_irs(const mc_engine *e);
+/* out[0..3] = sum h_L, sum h_R, sum h_L(-1)^m, sum h_R(-1)^m of the truncated IR; out[4] = taps, out[5] = partitions */
+int mc_ir_info(const mc_engine *e, uint64_t idx, double out[6]);
+
+int mc_set_params(mc_engine *e, int half, const mc_cc_value *v);
+int mc_get_params(const mc_engine *e, int half, mc_cc_value *v);
+/* handleCC (conv.cu:255-276): ccmap = controller numbers {select,predelay,dry,wet,speed,panDry,panWet,level} */
+int mc_handle_cc(mc_engine *e, int half, const uint8_t ccmap[8], uint8_t controller, int value);
+
+/* One JACK period: host buffers in, host buffers out, returns when the output
+ * is in outL/outR (like onProcess, which blocks on the GPU; conv.cu:455). */
+int mc_process(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nframes);
+/* nblocks consecutive periods, host buffers of nblocks*256 floats */
+int mc_process_batch(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nblocks);
+/* the same with device-resident buffers; asynchronous on the engine's stream */
+int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
+                            uint64_t nblocks);
+/* Sharded operation: d_partial receives this engine's share of the wet signal,
+ * 2*nblocks*256 floats ([L | R], pre-predelay); after the caller has summed the
+ * partials of all shards (RCCL all-reduce), mc_finish_batch_device applies
+ * predelay, Q1/Q2 terms, clamp and dry mix.  Every shard must see the same input. */
+int mc_partial_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_partial, uint64_t nblocks);
+int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, const float *d_wet_sum,
+                           float *d_outL, float *d_outR, uint64_t nblocks);
+
+int mc_sync(mc_engine *e);
+int mc_set_stream(mc_engine *e, void *hip_stream); /* NULL = engine-owned stream */
+void *mc_get_stream(mc_engine *e);
+double mc_avg_runtime_ms(const mc_engine *e);      /* mean ms per mc_process call after 10 warm-ups */
+int mc_enable_kernel_timing(mc_engine *e, int on); /* HIP events around the MAC kernel */
+int mc_get_kernel_stats(mc_engine *e, mc_kernel_stats *out, int reset);
+uint64_t mc_algorithmic_bytes_per_block(const mc_engine *e); /* (4 paths + 2 inputs) * P * 2048 */
+uint64_t mc_blocks_processed(const mc_engine *e);
+
+/* Diagnostics (tests only): copy `bytes` from an engine-owned device buffer to host.
+ * which: 0 = IR spectra of IR `idx` (float4 [256][pstride]), 1 = delay line
+ * (float4 [256][ring]), 2 = MAC output (float4 [256][max_batch]), 3 = segments,
+ * 4 = wet ring, 5 = Q1/Q2 prefix ring (double [rc][4]).  dims[0..3] receive
+ * {pstride, ring, max_batch, wet ring length} when non-null. */
+int mc_debug_read(mc_engine *e, int which, uint64_t idx, void *dst, uint64_t offset_bytes, uint64_t bytes,
+                  uint64_t dims[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+"""GPU parity tests: HIP engine (through the C ABI) vs the float64 oracle.
+
+Sizes are chosen so the oracle finishes in seconds; BASELINE-size cases use the
+partitioned oracle form (proven equal to the single-FFT restatement to 1e-16 in
+tests/test_oracle.py) and size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from helpers import BASE, RMS_TOL, apply_params, rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(**kw):
+    from cuda_audio_amd.engine import Convolution
+
+    return Convolution("test", **kw)
+
+
+def test_abi_loads_and_creates(gpu_lib):
+    assert gpu_lib.mc_abi_version() == 1
+    c = _conv(fftSize=4096, max_batch=8)
+    assert c.num_irs() == 0
+    c.close()
+
+
+def test_ir_spectra_match_numpy(gpu_lib):
+    """prepare(): per-partition 512-point spectra vs numpy rfft (conv.cu:207-253 restated per partition)."""
+    from cuda_audio_amd.synth import make_ir
+
+    ir = make_ir(1000, seed=3)
+    c = _conv(fftSize=4096, max_batch=8)
+    c.prepare(0, ir)
+    H = c.ir_spectra(0)  # [2][P][256]
+    P = H.shape[1]
+    assert P == 4
+    for ch in range(2):
+        for p in range(P):
+            seg = np.zeros(512)
+            part = ir[p * 256 : (p + 1) * 256, ch]
+            seg[: len(part)] = part
+            ref = np.fft.rfft(seg)
+            got = H[ch, p]
+            assert abs(got[0].real - ref[0].real) < 2e-5  # packed DC
+            assert abs(got[0].imag - ref[256].real) < 2e-5  # packed Nyquist
+            assert np.abs(got[1:] - ref[1:256]).max() < 2e-5
+    info = c.ir_info(0)
+    assert info["taps"] == 1000 and info["partitions"] == 4
+    np.testing.assert_allclose(info["sigma"], ir.astype(np.float64).sum(axis=0), rtol=1e-12)
+    c.close()
+
+
+CASES = {
+    "defaults": (dict(BASE), dict(BASE, select=1)),
+    "unequal": (
+        dict(BASE, predelay=300, wet=0.7, dry=0.3, panWet=0.25, panDry=-0.5, level=0.9),
+        dict(BASE, select=1, predelay=17, wet=0.4, dry=0.6, panWet=-0.75, panDry=0.1, level=0.8),
+    ),
+    "predelay1024": (dict(BASE, predelay=1024), dict(BASE, select=1)),
+    "hardpan": (dict(BASE, panWet=1.0, panDry=-1.0), dict(BASE, select=1, panWet=-1.0, panDry=1.0)),
+    "slowfade": (dict(BASE, vsteps=20), dict(BASE, select=1, vsteps=7)),
+}
+
+
+def _small_setup(oracle_mod, n_ref, nb, case, taps=(2500, 3072), three_mult=True):
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    x = make_input(nb * 256)
+    irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05)]
+    p0, p1 = CASES[case]
+    ref = oracle_mod.RefCompat(n_ref, three_mult)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    return x, irs, (p0, p1), ref.process(x[0], x[1])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_batch_matches_refcompat(oracle_mod, gpu_lib, case):
+    """Resident (batch) kernel path vs the single-FFT restatement, cold start, N_ref = 4096."""
+    nb = 96
+    x, irs, (p0, p1), want = _small_setup(oracle_mod, 4096, nb, case)
+    c = _conv(fftSize=4096, max_batch=48)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    got = c.process(x[0], x[1])
+    assert c.kernel_stats()["launches"] == 0
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"{case}: rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
+
+
+@pytest.mark.parametrize("case", ["defaults", "unequal", "slowfade"])
+def test_jack_path_matches_refcompat(oracle_mod, gpu_lib, case):
+    """onProcess (one block per call, streaming MAC kernel) vs the restatement."""
+    nb = 40
+    x, irs, (p0, p1), want = _small_setup(oracle_mod, 4096, nb, case)
+    c = _conv(fftSize=4096, max_batch=4)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    got = np.zeros((2, nb * 256), np.float32)
+    for b in range(nb):
+        s = slice(b * 256, (b + 1) * 256)
+        got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"{case}: rms {err:.3e}"
+    assert c.avgRuntime() > 0
+    c.close()
+
+
+def test_batch_split_invariance(gpu_lib):
+    """Same stream cut into different batch sizes (incl. ragged and stream-kernel sizes) gives the same output."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 150
+    x = make_input(nb * 256)
+    ir = make_ir(3000, seed=5, norm=0.05)
+    outs = []
+    for mb in (64, 37, 5):
+        c = _conv(fftSize=8192, max_batch=mb)
+        c.prepare(0, ir)
+        outs.append(c.process(x[0], x[1]))
+        c.close()
+    assert rms(outs[0] - outs[1]) < 2e-7
+    assert rms(outs[0] - outs[2]) < 2e-7
+
+
+def test_linear_mode_matches_direct_convolution(oracle_mod, gpu_lib):
+    """compat=0, config-1 shape: 1024-tap IR, exact time-domain convolution as ground truth."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 40
+    x = make_input(nb * 256)
+    ir = make_ir(1024, seed=9, norm=0.05)
+    c = _conv(fftSize=4096, max_batch=40, compat=False)
+    c.prepare(0, ir)
+    c.cc[0].value.update(dry=0.0, wet=1.0, vsteps=0)
+    c.cc[1].value.update(dry=0.0, wet=1.0, vsteps=0)
+    # settle the cross-fade (Q7) on silence, then run the signal
+    z = np.zeros(80 * 256, np.float32)
+    c.process(z, z)
+    got = c.process(x[0], x[1])
+    n = nb * 256
+    wantL = oracle_mod.direct_conv(x[0], ir[:, 0])[:n] + oracle_mod.direct_conv(x[1], ir[:, 0])[:n]
+    wantR = oracle_mod.direct_conv(x[0], ir[:, 1])[:n] + oracle_mod.direct_conv(x[1], ir[:, 1])[:n]
+    assert rms(got[0] - wantL) <= RMS_TOL and rms(got[1] - wantR) <= RMS_TOL
+    c.close()
+
+
+def test_config2_2s_ir(oracle_mod, gpu_lib):
+    """BASELINE config 2: stereo, 2 s IR (88 200 taps), N_ref = 131072; oracle = partitioned form."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 600
+    x = make_input(nb * 256)
+    ir = make_ir(88200, seed=5678, norm=0.02)
+    o = oracle_mod.Upols(131072, True)
+    o.prepare(0, ir)
+    want = o.process(x[0], x[1])
+    c = _conv(fftSize=131072, max_batch=256)
+    c.prepare(0, ir)
+    got = c.process(x[0], x[1])
+    assert np.abs(want).max() < 1.0
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
+
+
+def test_config3_10s_ir(oracle_mod, gpu_lib):
+    """BASELINE config 3 (headline): stereo, 10 s IR (441 000 taps, P = 1723), N_ref = 524288."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 768
+    x = make_input(nb * 256)
+    ir = make_ir(441000, seed=5678, norm=0.02)
+    o = oracle_mod.Upols(524288, True)
+    o.prepare(0, ir)
+    want = o.process(x[0], x[1])
+    c = _conv(fftSize=524288, max_batch=256)
+    c.prepare(0, ir)
+    assert c.ir_info(0)["partitions"] == 1723
+    assert c.algorithmic_bytes_per_block() == 6 * 1723 * 2048
+    got = c.process(x[0], x[1])
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
+
+
+def test_sharded_partials_sum_to_unsharded(gpu_lib):
+    """§8(e): G virtual shards on one device — sum of partial wet blocks then finish == unsharded engine."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, T = 128, 64
+    x = make_input(nb * 256)
+    ir = make_ir(20000, seed=7, norm=0.02)  # 79 partitions -> shards of 32
+    full = _conv(fftSize=32768, max_batch=T)
+    full.prepare(0, ir)
+    want = full.process(x[0], x[1])
+    full.close()
+    shards = [_conv(fftSize=32768, max_batch=T, part_begin=b, part_end=b + 32) for b in (0, 32, 64)]
+    for s in shards:
+        s.prepare(0, ir)
+    dev = torch.device("cuda:0")
+    got = np.zeros_like(want)
+    for o in range(0, nb, T):
+        xin = torch.from_numpy(x[:, o * 256 : (o + T) * 256].copy()).to(dev)
+        parts = [torch.zeros(2 * T * 256, device=dev) for _ in shards]
+        for s, p in zip(shards, parts):
+            s.partial_device(xin[0].data_ptr(), xin[1].data_ptr(), p.data_ptr(), T)
+            s.sync()
+        total = parts[0] + parts[1] + parts[2]
+        out = torch.zeros(2, T * 256, device=dev)
+        for s in shards:
+            s.finish_device(xin[0].data_ptr(), xin[1].data_ptr(), total.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), T)
+            s.sync()
+        got[:, o * 256 : (o + T) * 256] = out.cpu().numpy()
+    for s in shards:
+        s.close()
+    assert rms(got - want) < 5e-7
