@@ -6,6 +6,7 @@ is never imported from here.)
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmcconv.so")
@@ -79,6 +80,17 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m cuda_audio_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    # libamdhip64/libhsa-runtime64.  If libmcconv.so is loaded first it binds to
+    # /opt/rocm's copies and a later `import torch` finds "No HIP GPUs"; loaded
+    # after torch it binds (by soname) to torch's runtime, and stream handles
+    # and device pointers interoperate.  So when torch is installed, load it
+    # first.  Hosts without Python/torch (cuda_audio_amd/host) use /opt/rocm's.
+    if "torch" not in sys.modules and os.environ.get("MCCONV_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, fp, u64 = C.c_void_p, C.POINTER(C.c_float), C.c_uint64
     L.mc_abi_version.restype = C.c_uint32

@@ -1,0 +1,95 @@
+"""IR-partition sharding across the GPUs of one node.
+
+The output of the convolution is a sum over IR partitions, so partitions shard
+cleanly: rank g owns partitions [pb_g, pe_g) of every path.  Every rank sees the
+same input, runs the (cheap) forward FFT redundantly, its own share of the
+partition x bin MAC and the inverse FFT, and produces a partial wet block in
+the time domain.  The one exchange step is a sum of those partial blocks —
+an RCCL all-reduce over xGMI (torch.distributed backend "nccl") — after which
+every rank applies predelay, the Q1/Q2 terms, clamp and dry mix to the sum.
+The payload is 2 KB per block and rank, so batches are long (the message is
+nblocks * 2 KB) to keep the collective bandwidth- rather than latency-bound.
+
+The reference has no multi-GPU path (single device); this file is new.
+"""
+import torch
+
+BLOCK = 256
+ALIGN = 16  # shard bounds are multiples of 16 partitions (4 waves x 4-partition steps)
+
+
+def partitions_for(frames, fft_size, nframes=1024):
+    """Partitions of an IR after the reference's truncation (conv.cu:239)."""
+    n = min(int(frames), int(fft_size) - int(nframes))
+    return max(1, (n + BLOCK - 1) // BLOCK)
+
+
+def shard_bounds(n_partitions, world, rank):
+    """Contiguous, ALIGN-aligned partition range of `rank`; the union over ranks
+    covers [0, round_up(n_partitions, ALIGN)) exactly once.  May be empty for
+    trailing ranks when world * ALIGN > n_partitions."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    total = (n_partitions + ALIGN - 1) // ALIGN * ALIGN
+    per = ((total // ALIGN + world - 1) // world) * ALIGN
+    pb = min(rank * per, total)
+    pe = min(pb + per, total)
+    return pb, pe
+
+
+class HipShard:
+    """One rank's engine: cuda_audio_amd.Convolution restricted to its partition range."""
+
+    def __init__(self, fft_size, pb, pe, max_batch, device, compat=True):
+        from .engine import Convolution
+
+        if pe <= pb:
+            raise ValueError("empty shard: use fewer ranks than partitions / 16")
+        self.conv = Convolution("shard", fft_size, max_batch=max_batch, device=device, compat=compat,
+                                part_begin=pb, part_end=pe)
+        self.conv.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def prepare(self, idx, lr, nframes=1024):
+        self.conv.prepare(idx, lr, nframes)
+
+    def set_params(self, half, **kw):
+        self.conv.cc[half].value.update(**kw)
+
+    def partial(self, x, part, nblocks):
+        self.conv.partial_device(x[0].data_ptr(), x[1].data_ptr(), part.data_ptr(), nblocks)
+
+    def finish(self, x, wet_sum, out, nblocks):
+        self.conv.finish_device(x[0].data_ptr(), x[1].data_ptr(), wet_sum.data_ptr(), out[0].data_ptr(),
+                                out[1].data_ptr(), nblocks)
+
+    def close(self):
+        self.conv.close()
+
+
+class ShardedConvolution:
+    """Drives one shard per rank.  `shard` is a HipShard (product) or any object
+    with the same partial/finish interface (the gloo CPU tests inject an
+    oracle-backed one); `group` is a torch.distributed process group or None for
+    a single rank."""
+
+    def __init__(self, shard, world=1, group=None):
+        self.shard = shard
+        self.world = world
+        self.group = group
+
+    def process(self, x, out, part=None):
+        """x: [2, n] input (same on every rank), out: [2, n] output, n = nblocks * 256.
+        `part` is an optional preallocated [2 * n] scratch tensor for the partial."""
+        n = x.shape[1]
+        if n % BLOCK:
+            raise ValueError("length must be a multiple of 256")
+        nblocks = n // BLOCK
+        if part is None:
+            part = torch.empty(2 * n, dtype=out.dtype, device=x.device)
+        self.shard.partial(x, part, nblocks)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        self.shard.finish(x, part, out, nblocks)
+        return out

@@ -69,6 +69,9 @@ def lib():
     L.orc_upols_cc.restype = C.POINTER(CCValue)
     L.orc_upols_cc.argtypes = [C.c_void_p, C.c_int]
     L.orc_upols_process.argtypes = [C.c_void_p, fp, fp, dp, dp, C.c_size_t]
+    L.orc_upols_set_shard.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    L.orc_upols_partial.argtypes = [C.c_void_p, fp, fp, dp, dp]
+    L.orc_upols_finish.argtypes = [C.c_void_p, fp, fp, dp, dp, dp, dp]
     L.orc_cpu32_create.restype = C.c_void_p
     L.orc_cpu32_create.argtypes = [fp, fp, C.c_size_t]
     L.orc_cpu32_destroy.argtypes = [C.c_void_p]
@@ -201,8 +204,25 @@ class Upols(_Engine):
     _create, _destroy = "orc_upols_create", "orc_upols_destroy"
     _prepare, _cc, _process = "orc_upols_prepare", "orc_upols_cc", "orc_upols_process"
 
-    def __init__(self, n_ref, compat=True):
+    def __init__(self, n_ref, compat=True, part_begin=0, part_end=0):
         super().__init__(n_ref, 1 if compat else 0)
+        lib().orc_upols_set_shard(self._h, part_begin, part_end)
+
+    def partial(self, in1, in2):
+        """This shard's wet signal (pre-predelay) for consecutive blocks: float64 [2, n]."""
+        in1, in2 = _f32(in1), _f32(in2)
+        n = len(in1)
+        assert n == BLOCK, "partial/finish work one block at a time"
+        w = np.zeros((2, n), dtype=np.float64)
+        lib().orc_upols_partial(self._h, _fp(in1), _fp(in2), _dp(w[0]), _dp(w[1]))
+        return w
+
+    def finish(self, in1, in2, wsum):
+        in1, in2 = _f32(in1), _f32(in2)
+        wsum = np.ascontiguousarray(wsum, dtype=np.float64)
+        out = np.zeros((2, BLOCK), dtype=np.float64)
+        lib().orc_upols_finish(self._h, _fp(in1), _fp(in2), _dp(wsum[0]), _dp(wsum[1]), _dp(out[0]), _dp(out[1]))
+        return out
 
 
 class Cpu32:

@@ -400,7 +400,10 @@ struct orc_upols {
     cplx *X[2];           /* [i][t*UP_BINS + k] all block spectra so far */
     double *G;            /* [t*4 + c*2 + i] wet gains attached to input block t */
     double *CD, *CQ;      /* [t*2 + c] prefix sums of D_c, Q_c */
-    double *wet[2];       /* [c][tau] pre-delay wet stream, all samples so far */
+    double *wet[2];       /* [c][tau] pre-delay wet stream of THIS shard, all samples so far */
+    double *wsum[2];      /* [c][tau] wet stream summed over all shards (what the post stage reads) */
+    size_t pb, pe;        /* partition shard [pb, pe); pe == 0 means all */
+    int pending;          /* a partial block awaits its finish */
 };
 
 orc_upols *orc_upols_create(size_t n_ref, int compat) {
@@ -425,6 +428,8 @@ void orc_upols_destroy(orc_upols *u) {
     free(u->CQ);
     free(u->wet[0]);
     free(u->wet[1]);
+    free(u->wsum[0]);
+    free(u->wsum[1]);
     free(u);
 }
 
@@ -473,6 +478,8 @@ static void up_grow(orc_upols *u) {
         u->X[i] = (cplx *)realloc(u->X[i], sizeof(cplx) * nc * UP_BINS);
         u->wet[i] = (double *)realloc(u->wet[i], sizeof(double) * nc * UP_B);
         memset(u->wet[i] + u->cap * UP_B, 0, sizeof(double) * (nc - u->cap) * UP_B);
+        u->wsum[i] = (double *)realloc(u->wsum[i], sizeof(double) * nc * UP_B);
+        memset(u->wsum[i] + u->cap * UP_B, 0, sizeof(double) * (nc - u->cap) * UP_B);
     }
     u->G = (double *)realloc(u->G, sizeof(double) * nc * 4);
     u->CD = (double *)realloc(u->CD, sizeof(double) * nc * 2);
@@ -487,10 +494,14 @@ static inline long floordiv(long a, long b) {
     return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
 }
 
-void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double *outL, double *outR,
-                       size_t nframes) {
-    /* SURVEY Appendix B; nframes must be 256 */
-    if (nframes != UP_B) return;
+void orc_upols_set_shard(orc_upols *u, size_t pb, size_t pe) {
+    u->pb = pb;
+    u->pe = pe;
+}
+
+/* first half of a block: everything up to this shard's share of the wet block
+ * (pre-predelay), SURVEY Appendix B / §8(e) */
+void orc_upols_partial(orc_upols *u, const float *in1, const float *in2, double *wetL, double *wetR) {
     up_grow(u);
     size_t t = u->t;
     const float *in[2] = {in1, in2};
@@ -545,7 +556,8 @@ void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double 
         memset(Y, 0, sizeof(Y));
         for (int i = 0; i < 2; i++) {
             const up_ir *ir = irs[i];
-            for (size_t p = 0; p < ir->P && p <= t; p++) {
+            size_t p_lo = u->pb, p_hi = u->pe ? (u->pe < ir->P ? u->pe : ir->P) : ir->P;
+            for (size_t p = p_lo; p < p_hi && p <= t; p++) {
                 double g = u->G[(t - p) * 4 + c * 2 + i];
                 const cplx *Hp = ir->H[c] + p * UP_BINS;
                 const cplx *Xp = u->X[i] + (t - p) * UP_BINS;
@@ -561,6 +573,24 @@ void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double 
         }
     }
 
+    for (size_t m = 0; m < UP_B; m++) {
+        wetL[m] = u->wet[0][t * UP_B + m];
+        wetR[m] = u->wet[1][t * UP_B + m];
+    }
+    u->pending = 1;
+}
+
+/* second half: the wet block summed over all shards -> predelay, Q1/Q2 window
+ * sums, clamp, dry mix (conv.cu:411-427) */
+void orc_upols_finish(orc_upols *u, const float *in1, const float *in2, const double *wsumL, const double *wsumR,
+                      double *outL, double *outR) {
+    if (!u->pending) return;
+    size_t t = u->t;
+    orc_cc_value *cc = u->cc;
+    for (size_t m = 0; m < UP_B; m++) {
+        u->wsum[0][t * UP_B + m] = wsumL[m];
+        u->wsum[1][t * UP_B + m] = wsumR[m];
+    }
     /* predelay (half 0's, conv.cu:412,415), corrections, clamp, dry */
     long pd = (long)cc[0].predelay, N = (long)u->n_ref;
     double dgain[2][2];
@@ -572,7 +602,7 @@ void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double 
     for (int c = 0; c < 2; c++) {
         for (size_t m = 0; m < UP_B; m++) {
             long tau = (long)(t * UP_B + m);
-            double w = tau - pd >= 0 ? u->wet[c][tau - pd] : 0.0;
+            double w = tau - pd >= 0 ? u->wsum[c][tau - pd] : 0.0;
             /* blocks t' with pd <= tau - t'B < N  (shift by pd, cut at N: Q8) */
             long thi = floordiv(tau - pd, UP_B), tlo = floordiv(tau - N, UP_B);
             if (thi > (long)t) thi = (long)t;
@@ -584,6 +614,16 @@ void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double 
         }
     }
     u->t++;
+    u->pending = 0;
+}
+
+void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double *outL, double *outR,
+                       size_t nframes) {
+    /* SURVEY Appendix B; nframes must be 256 */
+    if (nframes != UP_B) return;
+    double wl[UP_B], wr[UP_B];
+    orc_upols_partial(u, in1, in2, wl, wr);
+    orc_upols_finish(u, in1, in2, wl, wr, outL, outR);
 }
 
 /* =============================================================== cpu32 ==== */

@@ -80,6 +80,12 @@ int orc_upols_prepare(orc_upols *u, size_t idx, const float *lr, size_t frames, 
 orc_cc_value *orc_upols_cc(orc_upols *u, int half);
 void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double *outL, double *outR,
                        size_t nframes);
+/* sharded form: partition range [pb, pe) (pe = 0: all); partial gives
+ * this shard's 256-sample wet block (pre-predelay), finish takes the sum over shards */
+void orc_upols_set_shard(orc_upols *u, size_t pb, size_t pe);
+void orc_upols_partial(orc_upols *u, const float *in1, const float *in2, double *wetL, double *wetR);
+void orc_upols_finish(orc_upols *u, const float *in1, const float *in2, const double *wsumL, const double *wsumR,
+                      double *outL, double *outR);
 
 /* ---- CPU baseline ("port"): float32 uniform-partition overlap-save, OpenMP
  * over bins, steady-state hot path only (fwd FFT, partition x bin MAC for the
