@@ -137,36 +137,56 @@ __device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, 
 // grid = 256 bins x ceil(T/256); block ids with equal bin share an XCD (id % 8).
 // ---------------------------------------------------------------------------
 #define MAC_PSEG 1024                       // partitions per LDS window segment
-#define MAC_WQ ((MAC_PSEG + 256 + 8) / 4)   // quarter-window length (entries)
+#define MAC_WQ ((MAC_PSEG + 256 + 16) / 4)  // quarter-window length (entries), incl. prefetch slack
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One wave's share of a window segment: partitions pse-1-q for q in [q_lo, q_hi).
+// Software-pipelined one iteration (4 partitions) ahead: the 64-byte scalar
+// loads of the next 4 partitions' spectra and the 4 ds_read_b128 of the next
+// window entries are issued before the 128 packed FMAs of the current step, so
+// the s_waitcnt at the top of the next iteration finds them complete.
 template <bool PACKED>
 __device__ __forceinline__ void mac_sweep(const float4* __restrict__ H0k, const float4* __restrict__ H1k, int pse,
                                           int q_lo, int q_hi, const float4* s_win, int lane, float2 (&acc)[4][4]) {
-    // window registers: entries 4*lane + q + 0..7
-    float4 w[8];
+    // window registers: w[0..6] = entries 4*lane + q + 0..6 (w[7] is the next iteration's w[3])
+    float4 w[8], wn[4];
     const float4* wbase = s_win + lane + (q_lo >> 2);
 #pragma unroll
     for (int u = 0; u < 4; u++) w[u] = wbase[u * MAC_WQ];
-    for (int q = q_lo; q < q_hi; q += 4) {
-        const float4* wn = s_win + lane + (q >> 2) + 1;
 #pragma unroll
-        for (int u = 0; u < 4; u++) w[4 + u] = wn[u * MAC_WQ];
-        const int pb = pse - 4 - q;  // partitions pb..pb+3, step u uses pb+3-u
+    for (int u = 0; u < 4; u++) w[4 + u] = wbase[u * MAC_WQ + 1];
+    // partitions pb..pb+3 of both IRs as one aligned 64-byte scalar load each
+    f32x16 hc0 = *reinterpret_cast<const f32x16*>(H0k + (pse - 4 - q_lo));
+    f32x16 hc1 = *reinterpret_cast<const f32x16*>(H1k + (pse - 4 - q_lo));
+    for (int q = q_lo; q < q_hi; q += 4) {
+        // prefetch for iteration q + 4 (clamped on the last one: loads stay in range, values unused)
+        const int qn = min(q + 4, q_hi - 4);
+        const f32x16 hn0 = *reinterpret_cast<const f32x16*>(H0k + (pse - 4 - qn));
+        const f32x16 hn1 = *reinterpret_cast<const f32x16*>(H1k + (pse - 4 - qn));
+        const float4* wp = s_win + lane + (q >> 2) + 2;
+#pragma unroll
+        for (int u = 0; u < 4; u++) wn[u] = wp[u * MAC_WQ];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const float4 h0 = H0k[pb + 3 - u];  // wave-uniform -> scalar loads
-            const float4 h1 = H1k[pb + 3 - u];
+            // step u uses partition pb + 3 - u = floats [4*(3-u) .. 4*(3-u)+3] of the 16
+            const int o = 4 * (3 - u);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float4 x = w[u + r];
-                cmac<PACKED>(acc[r][0], h0.x, h0.y, x.x, x.y);  // L <- in1 * h_sel0,L
-                cmac<PACKED>(acc[r][1], h1.x, h1.y, x.z, x.w);  // L <- in2 * h_sel1,L
-                cmac<PACKED>(acc[r][2], h0.z, h0.w, x.x, x.y);  // R <- in1 * h_sel0,R
-                cmac<PACKED>(acc[r][3], h1.z, h1.w, x.z, x.w);  // R <- in2 * h_sel1,R
+                cmac<PACKED>(acc[r][0], hc0[o + 0], hc0[o + 1], x.x, x.y);  // L <- in1 * h_sel0,L
+                cmac<PACKED>(acc[r][1], hc1[o + 0], hc1[o + 1], x.z, x.w);  // L <- in2 * h_sel1,L
+                cmac<PACKED>(acc[r][2], hc0[o + 2], hc0[o + 3], x.x, x.y);  // R <- in1 * h_sel0,R
+                cmac<PACKED>(acc[r][3], hc1[o + 2], hc1[o + 3], x.z, x.w);  // R <- in2 * h_sel1,R
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) w[u] = w[4 + u];
+        for (int u = 0; u < 4; u++) {
+            w[u] = w[4 + u];
+            w[4 + u] = wn[u];
+        }
+        hc0 = hn0;
+        hc1 = hn1;
     }
 }
 
@@ -199,7 +219,7 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
         const int nwin = seg + 256;
         const int sbase = slot0 + t0 - pse + 1;
         __syncthreads();  // previous segment's readers are done
-        for (int e = threadIdx.x; e < nwin + 4; e += 256) {
+        for (int e = threadIdx.x; e < nwin + 12; e += 256) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < nwin) x = fk[(sbase + e) & (ring - 1)];
             s_win[(e & 3) * MAC_WQ + (e >> 2)] = x;
