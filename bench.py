@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-block-per-call (JACK) measurement")
+    ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
+                    help="N > 1: sum of partial wet blocks to rank 0 (default) or to every rank")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the partial / collective / finish path even with one rank (rehearsal on one GPU)")
     return ap.parse_args()
 
 
@@ -93,8 +98,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    sharded = world > 1 or a.force_sharded
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     T = a.blocks
     ir = make_ir(a.taps, seed=5678)
@@ -125,22 +136,47 @@ def main():
     xs = make_input(n_distinct * T * BLOCK, seed=1234)
     d_in = torch.from_numpy(xs).to(dev)
     d_out = torch.zeros(2, T * BLOCK, device=dev)
-    d_part = torch.zeros(2 * T * BLOCK, device=dev) if world > 1 else None
+    d_parts = [torch.zeros(2 * T * BLOCK, device=dev) for _ in range(2)] if sharded else None
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    root_only = a.collective == "reduce"
+    pending = []
+
+    def retire():
+        # second half of the oldest batch in flight: wait for its collective, then predelay / clamp / dry on the sum
+        work, part, i1, i2 = pending.pop(0)
+        work.wait()  # makes the compute stream wait for the collective; the host does not block
+        if rank == 0 or not root_only:
+            eng.finish_device(i1, i2, part.data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+        else:
+            eng.finish_device(None, None, None, None, None, T)
 
     def step(k):
         o = (k % n_distinct) * T * BLOCK
         i1, i2 = d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr()
-        if world == 1:
+        if not sharded:
             eng.process_device(i1, i2, d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+            return
+        part = d_parts[k % 2]
+        eng.partial_device(i1, i2, part.data_ptr(), T)
+        if root_only:
+            work = dist.reduce(part, dst=0, async_op=True)
         else:
-            eng.partial_device(i1, i2, d_part.data_ptr(), T)
-            dist.all_reduce(d_part)
-            eng.finish_device(i1, i2, d_part.data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+            work = dist.all_reduce(part, async_op=True)
+        # the reduce of batch k overlaps the MAC of batch k+1: batch k-1 is finished now
+        if pending and not a.no_overlap:
+            retire()
+        pending.append((work, part, i1, i2))
+        if a.no_overlap:
+            retire()
+
+    def drain():
+        while pending:
+            retire()
 
     # settle the cold-start cross-fade (Q7) so the timed region is steady state
     for k in range(max(a.warmup, 1)):
         step(k)
+    drain()
     torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     eng.kernel_stats(reset=True)
@@ -150,6 +186,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -231,7 +268,9 @@ def main():
                 "partitions": P,
                 "paths": 4,
                 "mode": a.mode,
-                "parallelism": "single GPU" if world == 1 else f"IR partitions sharded over {world} GPUs + RCCL all-reduce of partial wet blocks",
+                "parallelism": "single GPU" if not sharded else
+                f"IR partitions sharded over {world} GPU(s) + RCCL {a.collective} of partial wet blocks"
+                f"{'' if a.no_overlap else ', overlapped with the next batch'}",
             },
             "roofline": {
                 "bound": "hbm",
@@ -257,7 +296,7 @@ def main():
         }
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -41,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kMaxIrs = 256;
 constexpr int kStageBufs = 4;
 constexpr int kEvPool = 1024;
+constexpr int kPipe = 2;
 
 inline uint32_t next_pow2(uint64_t v) {
     uint32_t p = 1;
@@ -88,13 +89,22 @@ struct mc_engine {
 
     // signal state
     double e[2] = {0, 0};  // cross-fade coefficient of each half's selected IR (Q7)
-    uint64_t t_abs = 0;    // blocks processed
-    bool uniform_valid = false;
-    BlockParams uniform_bp;
-    int cur_pstride = 1;
-    uint64_t cur_predelay = 0;
-    IrSums cur_irsums;
-    bool partial_pending = false;
+    uint64_t t_abs = 0;    // blocks finished (front + back done)
+    uint64_t t_front = 0;  // blocks whose front half (FFT, MAC, inverse, overlap-add) has been issued
+    // up to kPipe batches may sit between their front and back halves (sharded
+    // operation overlaps the cross-GPU reduce of batch k with the MAC of batch k+1)
+    struct BatchCtx {
+        int T = 0;
+        uint64_t t0 = 0;
+        int pstride = 1;
+        uint64_t predelay = 0;
+        IrSums irs;
+        int slot = 0;
+    } pipe[2];
+    int pipe_head = 0, pipe_count = 0;
+    uint64_t batch_seq = 0;
+    bool uniform_valid[2] = {false, false};
+    BlockParams uniform_bp[2];
 
     // avgRuntime (conv.cu:454-462): first 10 calls discarded
     double runtime_ms = 0;
@@ -143,9 +153,9 @@ int zero_state(mc_engine* e) {
     HIP_TRY(hipMemsetAsync(e->d_cring, 0, sizeof(double) * 4 * (size_t)e->rc, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->e[0] = e->e[1] = 0.0;
-    e->t_abs = 0;
-    e->uniform_valid = false;
-    e->partial_pending = false;
+    e->t_abs = e->t_front = 0;
+    e->uniform_valid[0] = e->uniform_valid[1] = false;
+    e->pipe_head = e->pipe_count = 0;
     return MC_OK;
 }
 
@@ -193,6 +203,10 @@ struct BatchCtx {
 // forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial
 int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin) {
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
+    if (e->pipe_count >= kPipe) return fail(MC_ERR_STATE, "%d batches already await mc_finish_batch_device", kPipe);
+    const int bslot = (int)(e->batch_seq % kPipe);
+    BlockParams* d_ptab = e->d_ptab + (size_t)bslot * e->Tmax;
+    float4* d_sums = e->d_sums + (size_t)bslot * e->Tmax;
     mc_cc_value cc[2];
     {
         std::lock_guard<std::mutex> lk(e->pmu);
@@ -222,31 +236,36 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         }
     }
     bool need_upload = true;
-    if (pstride == 0 && e->uniform_valid && std::memcmp(&e->uniform_bp, &tab[0], sizeof(BlockParams)) == 0) need_upload = false;
+    if (pstride == 0 && e->uniform_valid[bslot] && std::memcmp(&e->uniform_bp[bslot], &tab[0], sizeof(BlockParams)) == 0)
+        need_upload = false;
     if (need_upload) {
-        HIP_TRY(hipMemcpyAsync(e->d_ptab, tab, sizeof(BlockParams) * (size_t)ntab, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_ptab, tab, sizeof(BlockParams) * (size_t)ntab, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipEventRecord(e->ptab_ev[e->ptab_next], e->stream));
         e->ptab_ev_used[e->ptab_next] = true;
         e->ptab_next = (e->ptab_next + 1) % kStageBufs;
-        e->uniform_valid = (pstride == 0);
-        if (pstride == 0) e->uniform_bp = tab[0];
+        e->uniform_valid[bslot] = (pstride == 0);
+        if (pstride == 0) e->uniform_bp[bslot] = tab[0];
     }
-    e->cur_pstride = pstride;
-    e->cur_predelay = cc[0].predelay;
+    mc_engine::BatchCtx& ctx = e->pipe[(e->pipe_head + e->pipe_count) % kPipe];
+    ctx.T = T;
+    ctx.t0 = e->t_front;
+    ctx.pstride = pstride;
+    ctx.predelay = cc[0].predelay;
+    ctx.slot = bslot;
     for (int c = 0; c < 2; c++) {
-        e->cur_irsums.sig[0][c] = ir0.sums[c];
-        e->cur_irsums.sig[1][c] = ir1.sums[c];
-        e->cur_irsums.alp[0][c] = ir0.sums[2 + c];
-        e->cur_irsums.alp[1][c] = ir1.sums[2 + c];
+        ctx.irs.sig[0][c] = ir0.sums[c];
+        ctx.irs.sig[1][c] = ir1.sums[c];
+        ctx.irs.alp[0][c] = ir0.sums[2 + c];
+        ctx.irs.alp[1][c] = ir1.sums[2 + c];
     }
 
-    const int slot0 = (int)(e->t_abs & (uint64_t)(e->ring - 1));
-    const int seg0 = (int)(e->t_abs % (uint64_t)e->sr);
-    const int64_t tau0 = (int64_t)e->t_abs * MC_B;
+    const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
+    const int seg0 = (int)(e->t_front % (uint64_t)e->sr);
+    const int64_t tau0 = (int64_t)e->t_front * MC_B;
 
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
-                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, e->d_ptab, pstride, e->d_sums, e->d_slotpan, e->d_tw);
+                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotpan, e->d_tw);
 
     // partition range of this engine (shard), multiples of 16
     int p_hi = round_up(std::max(ir0.P, ir1.P), 16);
@@ -307,20 +326,34 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                        e->sr, seg0, e->d_tw);
     hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, e->d_wet, e->wr, tau0, lin);
     HIP_TRY(hipGetLastError());
+    e->pipe_count++;
+    e->batch_seq++;
+    e->t_front += (uint64_t)T;
     return MC_OK;
 }
 
-// Q1/Q2 prefix sums, predelay, clamp, dry mix; advances the block counter
+// Q1/Q2 prefix sums, predelay, clamp, dry mix of the oldest batch in flight.
+// d_outL == null: the caller does not need this engine's output (a non-root
+// rank of a reduce-to-root): nothing is launched, the batch is just retired.
 int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* lin_sum, float* d_outL, float* d_outR, int T) {
-    const int64_t tau0 = (int64_t)e->t_abs * MC_B;
-    if (lin_sum) hipLaunchKernelGGL(k_lin2ring, dim3(T), dim3(256), 0, e->stream, lin_sum, T, e->d_wet, e->wr, tau0);
-    hipLaunchKernelGGL(k_corr, dim3(1), dim3(256), 0, e->stream, e->d_sums, e->d_ptab, e->cur_pstride, T, e->cur_irsums,
-                       1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)e->t_abs);
-    hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_wet, e->wr, e->d_cring, e->rc, e->d_ptab, e->cur_pstride,
-                       d_in1, d_in2, d_outL, d_outR, T, (int64_t)e->t_abs, (int64_t)e->cur_predelay, (int64_t)e->cfg.n_ref,
-                       (int)e->cfg.compat);
-    HIP_TRY(hipGetLastError());
-    e->t_abs += (uint64_t)T;
+    if (!e->pipe_count) return fail(MC_ERR_STATE, "no batch awaits its second half");
+    const mc_engine::BatchCtx ctx = e->pipe[e->pipe_head];
+    if (ctx.T != T) return fail(MC_ERR_ARG, "finish of %d blocks but the pending batch has %d", T, ctx.T);
+    e->pipe_head = (e->pipe_head + 1) % kPipe;
+    e->pipe_count--;
+    if (d_outL && d_outR) {
+        const int64_t tau0 = (int64_t)ctx.t0 * MC_B;
+        const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
+        const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
+        if (lin_sum) hipLaunchKernelGGL(k_lin2ring, dim3(T), dim3(256), 0, e->stream, lin_sum, T, e->d_wet, e->wr, tau0);
+        hipLaunchKernelGGL(k_corr, dim3(1), dim3(256), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.irs,
+                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0);
+        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride,
+                           d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref,
+                           (int)e->cfg.compat);
+        HIP_TRY(hipGetLastError());
+    }
+    e->t_abs = ctx.t0 + (uint64_t)T;
     return MC_OK;
 }
 
@@ -423,11 +456,11 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_slotpan, sizeof(float4) * (size_t)e->ring));
     ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * e->Tmax));
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk));
-    ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
-    ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
     ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Tmax * MC_B, hipHostMallocDefault));
@@ -532,7 +565,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     ir.taps = n;
     ir.P = P;
     if ((int)idx + 1 > e->nirs) e->nirs = (int)idx + 1;
-    e->uniform_valid = false;
+    e->uniform_valid[0] = e->uniform_valid[1] = false;
     return MC_OK;
 }
 
@@ -616,24 +649,20 @@ int mc_process_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
 
 int mc_partial_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, float* d_partial, uint64_t nblocks) {
     if (!e || !d_in1 || !d_in2 || !d_partial) return fail(MC_ERR_ARG, "null argument");
-    if (e->partial_pending) return fail(MC_ERR_STATE, "previous partial batch not finished");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
-    int rc = run_front(e, d_in1, d_in2, T, d_partial);
-    if (rc) return rc;
-    e->partial_pending = true;
-    return MC_OK;
+    return run_front(e, d_in1, d_in2, T, d_partial);
 }
 
 int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, const float* d_wet_sum, float* d_outL,
                            float* d_outR, uint64_t nblocks) {
-    if (!e || !d_in1 || !d_in2 || !d_wet_sum || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
-    if (!e->partial_pending) return fail(MC_ERR_STATE, "no partial batch pending");
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    const bool want_out = d_outL || d_outR || d_wet_sum;
+    if (want_out && (!d_in1 || !d_in2 || !d_wet_sum || !d_outL || !d_outR)) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks outside range");
-    e->partial_pending = false;
-    return run_back(e, d_in1, d_in2, d_wet_sum, d_outL, d_outR, T);
+    return run_back(e, d_in1, d_in2, d_wet_sum, want_out ? d_outL : nullptr, d_outR, T);
 }
 
 int mc_sync(mc_engine* e) {

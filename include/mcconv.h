@@ -118,8 +118,12 @@ int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2
                             uint64_t nblocks);
 /* Sharded operation: d_partial receives this engine's share of the wet signal,
  * 2*nblocks*256 floats ([L | R], pre-predelay); after the caller has summed the
- * partials of all shards (RCCL all-reduce), mc_finish_batch_device applies
- * predelay, Q1/Q2 terms, clamp and dry mix.  Every shard must see the same input. */
+ * partials of all shards (RCCL reduce / all-reduce), mc_finish_batch_device applies
+ * predelay, Q1/Q2 terms, clamp and dry mix.  Every shard must see the same input.
+ * Up to two batches may be between their partial and their finish (finishes
+ * retire batches in order), so the reduce of batch k can overlap the MAC of
+ * batch k+1.  A rank that does not need the output (non-root of a reduce)
+ * passes NULL for d_wet_sum, d_outL and d_outR: the batch is retired, nothing runs. */
 int mc_partial_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_partial, uint64_t nblocks);
 int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, const float *d_wet_sum,
                            float *d_outL, float *d_outR, uint64_t nblocks);

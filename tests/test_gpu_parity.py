@@ -248,3 +248,52 @@ def test_sharded_partials_sum_to_unsharded(gpu_lib):
     for s in shards:
         s.close()
     assert rms(got - want) < 5e-7
+
+
+def test_two_batches_in_flight_and_retire_only(gpu_lib):
+    """Sharded pipeline: partial(k+1) may be issued before finish(k); a rank that does not need the output
+    retires batches with NULL buffers.  Results equal the plain batch call."""
+    import torch
+
+    from cuda_audio_amd._lib import McError
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, T = 96, 32
+    x = make_input(nb * 256)
+    ir = make_ir(6000, seed=7, norm=0.02)
+    plain = _conv(fftSize=16384, max_batch=T)
+    plain.prepare(0, ir)
+    want = plain.process(x[0], x[1])
+    plain.close()
+    dev = torch.device("cuda:0")
+    a = _conv(fftSize=16384, max_batch=T)  # keeps the output
+    b = _conv(fftSize=16384, max_batch=T)  # "non-root": retires only
+    for c in (a, b):
+        c.prepare(0, ir)
+    xin = torch.from_numpy(x).to(dev)
+    parts = [torch.zeros(2 * T * 256, device=dev) for _ in range(2)]
+    out = torch.zeros(2, nb * 256, device=dev)
+    nbat = nb // T
+    for k in range(nbat + 1):
+        if k < nbat:
+            s = xin[:, k * T * 256:(k + 1) * T * 256]
+            for c in (a, b):
+                c.partial_device(s[0].data_ptr(), s[1].data_ptr(), parts[k % 2].data_ptr(), T)
+                c.sync()
+        if k >= 1:
+            j = k - 1
+            s = xin[:, j * T * 256:(j + 1) * T * 256]
+            o = out[:, j * T * 256:(j + 1) * T * 256]
+            a.finish_device(s[0].data_ptr(), s[1].data_ptr(), parts[j % 2].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
+            b.finish_device(None, None, None, None, None, T)
+            a.sync()
+    assert a.blocks_processed() == nb and b.blocks_processed() == nb
+    assert rms(out.cpu().numpy() - want) < 1e-7
+    # a third partial without a finish is refused
+    s = xin[:, : T * 256]
+    a.partial_device(s[0].data_ptr(), s[1].data_ptr(), parts[0].data_ptr(), T)
+    a.partial_device(s[0].data_ptr(), s[1].data_ptr(), parts[1].data_ptr(), T)
+    with pytest.raises(McError):
+        a.partial_device(s[0].data_ptr(), s[1].data_ptr(), parts[0].data_ptr(), T)
+    a.close()
+    b.close()
