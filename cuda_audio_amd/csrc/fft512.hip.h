@@ -67,11 +67,25 @@ __device__ __forceinline__ float2 twiddle(const float2* tw, int idx) {
     return w;
 }
 
+// Ordering point between the LDS writes and reads of one exchange.  WG = true:
+// workgroup barrier (every wave of the workgroup runs the transform the same
+// number of times).  WG = false: only this wave takes part — LDS operations of
+// one wave execute in order, so a compiler-level fence plus a drained LDS queue
+// is enough and other waves may do something else meanwhile.
+template <bool WG>
+__device__ __forceinline__ void fft_sync() {
+    if (WG) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in lds[0..511].
 // tw = LDS table exp(-2 pi i m / 512).  `lds` is wave-private (FFT_WAVE_LDS
-// entries).  All waves of the workgroup must call this the same number of
-// times (it contains workgroup barriers).
-template <int DIR>
+// entries).
+template <int DIR, bool WG = true>
 __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* lds, const float2* tw, int lane) {
     // stage 1: DFT over n2, twiddle w512^(lane * k0)
     dft8<DIR>(v);
@@ -79,27 +93,27 @@ __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* lds, const f
     for (int k0 = 1; k0 < 8; k0++) v[k0] = cmul(v[k0], twiddle<DIR>(tw, lane * k0));
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0++) lds[k0 * FFT_ROW + lane] = v[k0];
-    __syncthreads();
+    fft_sync<WG>();
     const int a = lane >> 3, n0 = lane & 7;
 #pragma unroll
     for (int n1 = 0; n1 < 8; n1++) v[n1] = lds[a * FFT_ROW + n1 * 8 + n0];
-    __syncthreads();
+    fft_sync<WG>();
     // stage 2: DFT over n1, twiddle w64^(n0 * k1)
     dft8<DIR>(v);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) v[k1] = cmul(v[k1], twiddle<DIR>(tw, 8 * n0 * k1));
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) lds[a * FFT_ROW + k1 * 8 + n0] = v[k1];
-    __syncthreads();
+    fft_sync<WG>();
     // lane = 8 k0 + k1 now reads its 8 consecutive n0 values
 #pragma unroll
     for (int m = 0; m < 8; m++) v[m] = lds[a * FFT_ROW + n0 * 8 + m];
-    __syncthreads();
+    fft_sync<WG>();
     // stage 3: DFT over n0 -> X[k0 + 8 k1 + 64 k2]
     dft8<DIR>(v);
 #pragma unroll
     for (int k2 = 0; k2 < 8; k2++) lds[a + 8 * n0 + 64 * k2] = v[k2];
-    __syncthreads();
+    fft_sync<WG>();
 }
 
 // stage the twiddle table into LDS (all threads of the workgroup)

@@ -267,10 +267,14 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
 // the slot's input block is applied per term (exact for time-varying pans).
 // grid = (256 bins, nchunk, T); partial sums per chunk are added by k_inv.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mac_stream(const float4* __restrict__ H0, const float4* __restrict__ H1,
+#define STREAM_U 4  // partitions per lane and loop trip, all loads issued before the first use
+
+template <bool UNIFORM_PAN, int NT>
+__global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0, const float4* __restrict__ H1,
                                                     int pstride_ir, int p_begin, int p_end, int chunk,
                                                     const float4* __restrict__ fdl, const float4* __restrict__ slotpan,
-                                                    int ring, int slot0, float4* __restrict__ part, int nchunk) {
+                                                    int ring, int slot0, float4* __restrict__ part, int nchunk,
+                                                    float4 upan) {
     const int bin = blockIdx.x, ch = blockIdx.y, t = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* H0k = H0 + (size_t)bin * pstride_ir;
@@ -280,27 +284,39 @@ __global__ __launch_bounds__(256) void k_mac_stream(const float4* __restrict__ H
     const int st = slot0 + t;
     float2 yl = make_float2(0.f, 0.f), yr = make_float2(0.f, 0.f);
     const bool packed = (bin == 0);
-    for (int p = lo + (int)threadIdx.x; p < hi; p += 256) {
-        const int slot = (st - p) & (ring - 1);
-        const float4 x = fk[slot];
-        const float4 g = slotpan[slot];
-        const float4 h0 = H0k[p], h1 = H1k[p];
-        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        if (packed) {
-            cmac<true>(a0, h0.x, h0.y, x.x, x.y);
-            cmac<true>(a1, h1.x, h1.y, x.z, x.w);
-            cmac<true>(a2, h0.z, h0.w, x.x, x.y);
-            cmac<true>(a3, h1.z, h1.w, x.z, x.w);
-        } else {
-            cmac<false>(a0, h0.x, h0.y, x.x, x.y);
-            cmac<false>(a1, h1.x, h1.y, x.z, x.w);
-            cmac<false>(a2, h0.z, h0.w, x.x, x.y);
-            cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+    for (int p0 = lo + (int)threadIdx.x; p0 < hi; p0 += NT * STREAM_U) {
+        float4 x[STREAM_U], g[STREAM_U], h0[STREAM_U], h1[STREAM_U];
+#pragma unroll
+        for (int u = 0; u < STREAM_U; u++) {
+            const int p = min(p0 + NT * u, hi - 1);  // clamped: the load is always in range, masked below
+            const int slot = (st - p) & (ring - 1);
+            x[u] = fk[slot];
+            g[u] = upan;  // pans unchanged over the whole window: one value for every slot
+            if (!UNIFORM_PAN) g[u] = slotpan[slot];
+            h0[u] = H0k[p];
+            h1[u] = H1k[p];
         }
-        yl.x += g.x * a0.x + g.y * a1.x;
-        yl.y += g.x * a0.y + g.y * a1.y;
-        yr.x += g.z * a2.x + g.w * a3.x;
-        yr.y += g.z * a2.y + g.w * a3.y;
+#pragma unroll
+        for (int u = 0; u < STREAM_U; u++) {
+            if (p0 + NT * u < hi) {
+                float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                if (packed) {
+                    cmac<true>(a0, h0[u].x, h0[u].y, x[u].x, x[u].y);
+                    cmac<true>(a1, h1[u].x, h1[u].y, x[u].z, x[u].w);
+                    cmac<true>(a2, h0[u].z, h0[u].w, x[u].x, x[u].y);
+                    cmac<true>(a3, h1[u].z, h1[u].w, x[u].z, x[u].w);
+                } else {
+                    cmac<false>(a0, h0[u].x, h0[u].y, x[u].x, x[u].y);
+                    cmac<false>(a1, h1[u].x, h1[u].y, x[u].z, x[u].w);
+                    cmac<false>(a2, h0[u].z, h0[u].w, x[u].x, x[u].y);
+                    cmac<false>(a3, h1[u].z, h1[u].w, x[u].z, x[u].w);
+                }
+                yl.x += g[u].x * a0.x + g[u].y * a1.x;
+                yl.y += g[u].x * a0.y + g[u].y * a1.y;
+                yr.x += g[u].z * a2.x + g[u].w * a3.x;
+                yr.y += g[u].z * a2.y + g[u].w * a3.y;
+            }
+        }
     }
     // wavefront butterfly reduction (64 lanes), then 4 waves through LDS
     float v[4] = {yl.x, yl.y, yr.x, yr.y};
@@ -309,18 +325,21 @@ __global__ __launch_bounds__(256) void k_mac_stream(const float4* __restrict__ H
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_xor(v[c], off, 64);
     }
-    __shared__ float s_red[4][4];
+    __shared__ float s_red[NT / 64][4];
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 4; c++) s_red[wave][c] = v[c];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float4 o;
-        o.x = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-        o.y = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-        o.z = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
-        o.w = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+            o.x += s_red[w][0];
+            o.y += s_red[w][1];
+            o.z += s_red[w][2];
+            o.w += s_red[w][3];
+        }
         part[((size_t)t * MC_NB + bin) * nchunk + ch] = o;
     }
 }
@@ -535,4 +554,203 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ wet, int
     float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
     outL[i] = vl + x1 * bp.d[0] + x2 * bp.d[1];
     outR[i] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+}
+
+// ---------------------------------------------------------------------------
+// Single-block (JACK) path.  k_mac_stream sums partitions p >= 1, which depend
+// only on blocks already in the delay line; this kernel does everything that
+// needs the new block, in one workgroup:
+//   wave 0: forward transform of the block (read straight from mapped host
+//           memory), delay-line slot, S/A sums          | waves 1-3: add the chunk partials
+//   all   : p = 0 term  H_{.,.,0} (x) X[t]  for the 256 bins
+//   wave 0: packed inverse transform
+//   all   : overlap-add with the previous tail, Q1/Q2 prefix update, predelay,
+//           clamp, dry mix, output straight to mapped host memory.
+// Replaces, for nframes = 256, the whole body of onProcess (conv.cu:321-451).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, const float* __restrict__ in2,
+                                               const float4* __restrict__ H0, const float4* __restrict__ H1,
+                                               int pstride_ir, int do_p0, float4* __restrict__ fdl,
+                                               float4* __restrict__ slotpan, int ring, int slot0,
+                                               const float4* __restrict__ part, int nchunk, int have_part,
+                                               const BlockParams* __restrict__ ptab, float* __restrict__ seg, int sr,
+                                               int seg0, float* __restrict__ wet, int wr, double* __restrict__ cring,
+                                               int rc, IrSums irs, double inv_n, int compat, int64_t tabs0,
+                                               int64_t predelay, int64_t n_ref, float* __restrict__ outL,
+                                               float* __restrict__ outR, const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[FFT_WAVE_LDS];
+    __shared__ float4 s_x[MC_NB];   // scaled spectra of the new block {X1, X2}
+    __shared__ float4 s_y[MC_NB];   // Y_L, Y_R
+    __shared__ float s_wet[2][MC_B];
+    __shared__ float s_in[2][MC_B];
+    __shared__ double s_c[4];
+    __shared__ float4 s_sa;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlockParams bp = ptab[0];
+    load_twiddles(s_tw, g_tw);
+    s_in[0][tid] = in1[tid];
+    s_in[1][tid] = in2[tid];
+    __syncthreads();
+    if (wave == 0) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = make_float2(s_in[0][lane + 64 * r], s_in[1][lane + 64 * r]);
+#pragma unroll
+        for (int r = 4; r < 8; r++) v[r] = make_float2(0.f, 0.f);
+        fft512_wave<-1, false>(v, s_fft, s_tw, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = lane + 64 * j;
+            const float2 za = s_fft[k], zb = s_fft[(FFT_N - k) & (FFT_N - 1)];
+            float2 x1, x2;
+            if (k == 0) {
+                const float2 zn = s_fft[MC_B];
+                x1 = make_float2(za.x, zn.x);
+                x2 = make_float2(za.y, zn.y);
+                s_sa = make_float4(za.x, za.y, zn.x, zn.y);
+            } else {
+                x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
+                x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
+            }
+            const float4 xs = make_float4(x1.x * bp.s[0], x1.y * bp.s[0], x2.x * bp.s[1], x2.y * bp.s[1]);
+            s_x[k] = xs;
+            fdl[(size_t)k * ring + slot0] = xs;
+        }
+        if (lane == 0) slotpan[slot0] = make_float4(bp.pan[0], bp.pan[1], bp.pan[2], bp.pan[3]);
+    } else {
+        for (int k = tid - 64; k < MC_NB; k += 192) {
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have_part) {
+                const float4* src = part + (size_t)k * nchunk;
+                for (int c = 0; c < nchunk; c++) {
+                    const float4 a = src[c];
+                    y.x += a.x;
+                    y.y += a.y;
+                    y.z += a.z;
+                    y.w += a.w;
+                }
+            }
+            s_y[k] = y;
+        }
+    }
+    __syncthreads();
+    if (do_p0) {  // partition 0 of both IRs against the new block
+        const int k = tid;
+        const float4 x = s_x[k];
+        const float4 h0 = H0[(size_t)k * pstride_ir], h1 = H1[(size_t)k * pstride_ir];
+        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        if (k == 0) {
+            cmac<true>(a0, h0.x, h0.y, x.x, x.y);
+            cmac<true>(a1, h1.x, h1.y, x.z, x.w);
+            cmac<true>(a2, h0.z, h0.w, x.x, x.y);
+            cmac<true>(a3, h1.z, h1.w, x.z, x.w);
+        } else {
+            cmac<false>(a0, h0.x, h0.y, x.x, x.y);
+            cmac<false>(a1, h1.x, h1.y, x.z, x.w);
+            cmac<false>(a2, h0.z, h0.w, x.x, x.y);
+            cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+        }
+        float4 y = s_y[k];
+        y.x += bp.pan[0] * a0.x + bp.pan[1] * a1.x;
+        y.y += bp.pan[0] * a0.y + bp.pan[1] * a1.y;
+        y.z += bp.pan[2] * a2.x + bp.pan[3] * a3.x;
+        y.w += bp.pan[2] * a2.y + bp.pan[3] * a3.y;
+        s_y[k] = y;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n = lane + 64 * r;
+            float2 w;
+            if (n == 0) {
+                const float4 y = s_y[0];
+                w = make_float2(y.x, y.z);
+            } else if (n == MC_B) {
+                const float4 y = s_y[0];
+                w = make_float2(y.y, y.w);
+            } else if (n < MC_B) {
+                const float4 y = s_y[n];
+                w = make_float2(y.x - y.w, y.y + y.z);
+            } else {
+                const float4 y = s_y[FFT_N - n];
+                w = make_float2(y.x + y.w, -y.y + y.z);
+            }
+            v[r] = w;
+        }
+        fft512_wave<+1, false>(v, s_fft, s_tw, lane);
+    }
+    __syncthreads();
+    {
+        // overlap-add with the previous block's tail; this block's segments go to the ring
+        const int m = tid;
+        const float sc = 1.0f / FFT_N;
+        const float2 lo = s_fft[m], hi = s_fft[MC_B + m];
+        float* cur = seg + (size_t)seg0 * 2 * FFT_N;
+        const float* prv = seg + (size_t)((seg0 + sr - 1) % sr) * 2 * FFT_N;
+        const float wl = lo.x * sc + prv[MC_B + m], wr_ = lo.y * sc + prv[FFT_N + MC_B + m];
+        cur[m] = lo.x * sc;
+        cur[MC_B + m] = hi.x * sc;
+        cur[FFT_N + m] = lo.y * sc;
+        cur[FFT_N + MC_B + m] = hi.y * sc;
+        const int64_t tau = tabs0 * MC_B + m;
+        wet[(size_t)(tau & (wr - 1))] = wl;
+        wet[(size_t)wr + (tau & (wr - 1))] = wr_;
+        s_wet[0][m] = wl;
+        s_wet[1][m] = wr_;
+        if (m == 0) {
+            double d[4] = {0, 0, 0, 0};
+            if (compat) corr_terms(s_sa, bp, irs, inv_n, d);
+            const double* pb = cring + (size_t)((tabs0 + rc - 1) % rc) * 4;
+            double* o = cring + (size_t)(tabs0 % rc) * 4;
+            for (int c = 0; c < 4; c++) {
+                const double vv = (tabs0 > 0 ? pb[c] : 0.0) + d[c];
+                o[c] = vv;
+                s_c[c] = vv;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int m = tid;
+        const int64_t tau = tabs0 * MC_B + m;
+        const int64_t u = tau - predelay;
+        float wl = 0.f, wr_ = 0.f;
+        if (u >= 0) {
+            if (u >= tabs0 * MC_B) {  // inside this block: not yet visible through global memory
+                wl = s_wet[0][u - tabs0 * MC_B];
+                wr_ = s_wet[1][u - tabs0 * MC_B];
+            } else {
+                wl = wet[(size_t)(u & (wr - 1))];
+                wr_ = wet[(size_t)wr + (u & (wr - 1))];
+            }
+        }
+        double cl = 0.0, cr = 0.0;
+        if (compat && u >= 0) {
+            const int64_t thi = u >> 8;
+            const int64_t vv = tau - n_ref;
+            const int64_t tlo = vv >= 0 ? (vv >> 8) : -1;
+            double a[4];
+            if (thi == tabs0) {
+                for (int c = 0; c < 4; c++) a[c] = s_c[c];
+            } else {
+                const double* pa = cring + (size_t)(thi % rc) * 4;
+                for (int c = 0; c < 4; c++) a[c] = pa[c];
+            }
+            if (tlo >= 0) {
+                const double* b = cring + (size_t)(tlo % rc) * 4;
+                for (int c = 0; c < 4; c++) a[c] -= b[c];
+            }
+            const double sg = (u & 1) ? -1.0 : 1.0;
+            cl = a[0] + sg * a[2];
+            cr = a[1] + sg * a[3];
+        }
+        const float x1 = s_in[0][m], x2 = s_in[1][m];
+        const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
+        const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
+        outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
+        outR[m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+    }
 }

@@ -297,3 +297,79 @@ def test_two_batches_in_flight_and_retire_only(gpu_lib):
         a.partial_device(s[0].data_ptr(), s[1].data_ptr(), parts[0].data_ptr(), T)
     a.close()
     b.close()
+
+
+def test_jack_path_pan_change_is_exact(oracle_mod, gpu_lib):
+    """panWet / level / dry changes between periods: the streaming path keeps per-block pans with the delay
+    line (and speculates the next period's sweep), so it follows the reference exactly, where the values
+    current at block t scale the whole contribution of input block t (conv.cu:386-401)."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 60, 8192
+    x = make_input(nb * 256)
+    irs = [make_ir(5000, seed=11, norm=0.05), make_ir(4000, seed=22, norm=0.05)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=4)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    ref.set(1, select=1)
+    c.cc[1].value.select = 1
+    events = {12: (0, dict(panWet=0.5)), 20: (1, dict(panWet=-0.25, level=0.7)), 33: (0, dict(dry=0.1, panDry=0.75)),
+              41: (0, dict(panWet=-1.0))}
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    for b in range(nb):
+        if b in events:
+            half, kw = events[b]
+            ref.set(half, **kw)
+            c.cc[half].value.update(**kw)
+        s = slice(b * 256, (b + 1) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e}"
+    c.close()
+
+
+def test_speculative_sweep_is_invisible(gpu_lib):
+    """The next period's partition sweep is launched speculatively after each period; an IR switch, a batch call
+    or a reset in between must invalidate it.  Same events with speculation disabled give identical samples."""
+    import os
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 50
+    x = make_input(nb * 256)
+    irs = [make_ir(5000, seed=11, norm=0.05), make_ir(4000, seed=22, norm=0.05)]
+
+    def run(no_spec):
+        if no_spec:
+            os.environ["MCCONV_NO_SPECULATE"] = "1"
+        else:
+            os.environ.pop("MCCONV_NO_SPECULATE", None)
+        c = _conv(fftSize=8192, max_batch=8)
+        os.environ.pop("MCCONV_NO_SPECULATE", None)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        out = np.zeros((2, nb * 256), np.float32)
+        b = 0
+        while b < nb:
+            if b == 10:
+                c.cc[0].value.select = 1  # IR switch: the speculated sweep used the old IR
+            if b == 20:  # a batch call in the middle of single periods
+                s = slice(b * 256, (b + 6) * 256)
+                out[:, s] = c.process(x[0, s], x[1, s])
+                b += 6
+                continue
+            if b == 35:
+                c.prepare(1, irs[0])  # reload an IR in place
+            s = slice(b * 256, (b + 1) * 256)
+            out[0, s], out[1, s] = c.onProcess(x[0, s], x[1, s])
+            b += 1
+        c.close()
+        return out
+
+    a, bb = run(False), run(True)
+    assert np.abs(a).max() > 0.01
+    assert rms(a - bb) < 1e-7
