@@ -19,7 +19,8 @@
 #define MC_B 256
 #define MC_K 512
 #define MC_NB 256
-#define FWD_TILE 16  // blocks per workgroup of the forward / inverse transform kernels
+#define FWD_TILE 8   // blocks per workgroup of the forward / inverse transform kernels (2 per wave)
+#define FWD_TILE_LOG2 3
 
 // Per-block parameters computed on the host in double (Q7 ramp, pans, levels)
 struct BlockParams {
@@ -36,7 +37,7 @@ struct BlockParams {
 // 321-328, 367-371) for one zero-padded 256-frame block per wave pass.  The
 // same kernel prepares IR partitions (conv.cu:207-253): the IR's L/R channels
 // are the two "inputs", slot = partition index, unit scale.
-// grid = ceil(T / 16), block = 256 (4 waves x 4 transforms each).
+// grid = ceil(T / 8), block = 256 (4 waves x 2 transforms each).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
                                              int in_stride,  // floats between successive frames (1, or 2 for interleaved IR)
@@ -100,9 +101,9 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
         __syncthreads();  // lds reused by the next transform
     }
     __syncthreads();
-    // transposed, coalesced store: 16 consecutive slots (256 B) per bin
+    // transposed, coalesced store: 8 consecutive slots (128 B) per bin
     for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
-        int tb = idx & (FWD_TILE - 1), k = idx >> 4;
+        int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         if (t < T) fdl[(size_t)k * ring + ((slot0 + t) & (ring - 1))] = s_tile[k][tb];
     }
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0
 // 512-point inverse per block, real part = left segment, imaginary = right
 // (replaces the two cufftExecC2C inverse calls, conv.cu:403-408).
 // Y element (bin k, block t) = sum_{c<nsum} Ysrc[k*sk + t*st + c].
-// seg[(seg0 + t) mod sr][ch][512].   grid = ceil(T/16), block = 256.
+// seg[(seg0 + t) mod sr][ch][512].   grid = ceil(T/8), block = 256.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int T,
                                              float* __restrict__ seg, int sr, int seg0,
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
     load_twiddles(s_tw, g_tw);
     const int tb0 = blockIdx.x * FWD_TILE;
     for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
-        int tb = idx & (FWD_TILE - 1), k = idx >> 4;
+        int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < T) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
         }
         fft512_wave<+1>(v, lds, s_tw, lane);
         if (t < T) {
-            float* dst = seg + (size_t)((seg0 + t) % sr) * 2 * FFT_N;
+            float* dst = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
             const float sc = 1.0f / FFT_N;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -417,34 +418,28 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
     }
 }
 
-// ---------------------------------------------------------------------------
-// K4: overlap-add of the segments into the wet stream (pre-predelay).
-// Output either into the wet ring (absolute sample index mod WR) or into a
-// caller-provided linear buffer [2][T*256] (sharded operation).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T,
-                                             float* __restrict__ wet, int wr, int64_t tau0,  // ring mode
-                                             float* __restrict__ lin) {                         // linear mode (or null)
-    const int t = blockIdx.x, m = threadIdx.x;
-    const float* cur = seg + (size_t)((seg0 + t) % sr) * 2 * FFT_N;
-    const float* prv = seg + (size_t)((seg0 + t + sr - 1) % sr) * 2 * FFT_N;
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        float v = cur[c * FFT_N + m] + prv[c * FFT_N + MC_B + m];
-        if (lin)
-            lin[(size_t)c * T * MC_B + (size_t)t * MC_B + m] = v;
-        else
-            wet[(size_t)c * wr + ((tau0 + (int64_t)t * MC_B + m) & (wr - 1))] = v;
-    }
+// Wet signal of sample (t, m) of the current batch: either the overlap-add of
+// this block's first half with the previous block's second half straight from
+// the segment ring (single engine), or the caller's summed linear buffer (shards).
+__device__ __forceinline__ float2 batch_wet(const float* __restrict__ seg, int sr, int seg0, const float* __restrict__ lin,
+                                            int T, int t, int m) {
+    if (lin) return make_float2(lin[(size_t)t * MC_B + m], lin[(size_t)T * MC_B + (size_t)t * MC_B + m]);
+    const float* cur = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
+    const float* prv = seg + (size_t)((seg0 + t + sr - 1) & (sr - 1)) * 2 * FFT_N;
+    return make_float2(cur[m] + prv[MC_B + m], cur[FFT_N + m] + prv[FFT_N + MC_B + m]);
 }
 
-// copy a summed linear wet buffer [2][T*256] into the wet ring
-__global__ __launch_bounds__(256) void k_lin2ring(const float* __restrict__ lin, int T, float* __restrict__ wet, int wr,
-                                                  int64_t tau0) {
+// ---------------------------------------------------------------------------
+// K4 (sharded operation only): overlap-add of this shard's segments into the
+// caller's linear partial buffer [2][T*256] that goes into the cross-GPU sum.
+// (A single engine needs no such pass: k_post overlap-adds straight from the
+// segment ring.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T, float* __restrict__ lin) {
     const int t = blockIdx.x, m = threadIdx.x;
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-        wet[(size_t)c * wr + ((tau0 + (int64_t)t * MC_B + m) & (wr - 1))] = lin[(size_t)c * T * MC_B + (size_t)t * MC_B + m];
+    const float2 w = batch_wet(seg, sr, seg0, nullptr, T, t, m);
+    lin[(size_t)t * MC_B + m] = w.x;
+    lin[(size_t)T * MC_B + (size_t)t * MC_B + m] = w.y;
 }
 
 // ---------------------------------------------------------------------------
@@ -468,44 +463,59 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
     d[3] = -(bp.G[2] * A1 * irs.alp[0][1] + bp.G[3] * A2 * irs.alp[1][1]) * inv_n;
 }
 
-__global__ __launch_bounds__(256) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
-                                              int pstride, int T, IrSums irs, double inv_n, int compat,
-                                              double* __restrict__ cring, int rc, int64_t tabs0) {
-    // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc)
-    __shared__ double s_part[256][4];
+#define CORR_NT 1024      // one workgroup
+#define CORR_PER_MAX 4    // blocks per thread: T <= 1024 * 4
+
+__global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
+                                                  int pstride, int T, IrSums irs, double inv_n, int compat,
+                                                  double* __restrict__ cring, int rc, int64_t tabs0) {
+    // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc).
+    // Thread tid owns the `per` consecutive blocks tid*per ..; their loads are issued together, running
+    // sums stay in registers, one 1024-wide scan joins the threads.  (Small code on purpose: a
+    // single-workgroup kernel this short is bound by instruction fetch, not by arithmetic.)
+    __shared__ double s_part[CORR_NT][4];
     const int tid = threadIdx.x;
-    const int per = (T + 255) / 256;
+    const int per = (T + CORR_NT - 1) / CORR_NT;
+    double loc[CORR_PER_MAX][4];
     double run[4] = {0, 0, 0, 0};
-    if (compat) {
-        for (int j = 0; j < per; j++) {
-            const int t = tid * per + j;
-            if (t < T) {
-                double d[4];
-                corr_terms(sums[t], ptab[(int64_t)t * pstride], irs, inv_n, d);
-                for (int c = 0; c < 4; c++) run[c] += d[c];
-            }
+#pragma unroll
+    for (int j = 0; j < CORR_PER_MAX; j++) {
+        const int t = tid * per + j;
+        const bool ok = j < per && t < T && compat;
+        const int tc = min(t, T - 1);  // clamped, unconditional loads; masked by select
+        const float4 v = sums[tc];
+        const BlockParams* bp = ptab + (int64_t)tc * pstride;
+        double d[4] = {0, 0, 0, 0};
+        corr_terms(v, *bp, irs, inv_n, d);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            run[c] += ok ? d[c] : 0.0;
+            loc[j][c] = run[c];
         }
     }
     for (int c = 0; c < 4; c++) s_part[tid][c] = run[c];
     __syncthreads();
+    for (int off = 1; off < CORR_NT; off <<= 1) {  // inclusive Hillis-Steele scan of the per-thread totals
+        double v[4] = {0, 0, 0, 0};
+        if (tid >= off)
+            for (int c = 0; c < 4; c++) v[c] = s_part[tid - off][c];
+        __syncthreads();
+        for (int c = 0; c < 4; c++) s_part[tid][c] += v[c];
+        __syncthreads();
+    }
     double base[4] = {0, 0, 0, 0};
     if (tabs0 > 0) {
-        const double* p = cring + (size_t)((tabs0 - 1) % rc) * 4;
+        const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) base[c] = p[c];
     }
-    for (int i = 0; i < tid; i++)
-        for (int c = 0; c < 4; c++) base[c] += s_part[i][c];
-    // second pass: recompute the terms and write the running sums
-    for (int j = 0; j < per; j++) {
+    for (int c = 0; c < 4; c++) base[c] += s_part[tid][c] - run[c];  // exclusive prefix of this thread
+#pragma unroll
+    for (int j = 0; j < CORR_PER_MAX; j++) {
         const int t = tid * per + j;
-        if (t < T) {
-            if (compat) {
-                double d[4];
-                corr_terms(sums[t], ptab[(int64_t)t * pstride], irs, inv_n, d);
-                for (int c = 0; c < 4; c++) base[c] += d[c];
-            }
-            double* o = cring + (size_t)((tabs0 + t) % rc) * 4;
-            for (int c = 0; c < 4; c++) o[c] = base[c];
+        if (j < per && t < T) {
+            double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) o[c] = base[c] + loc[j][c];
         }
     }
 }
@@ -515,17 +525,28 @@ __global__ __launch_bounds__(256) void k_corr(const float4* __restrict__ sums, c
 // (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
 // conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_post(const float* __restrict__ wet, int wr, const double* __restrict__ cring,
-                                              int rc, const BlockParams* __restrict__ ptab, int pstride,
+__global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, int seg0, const float* __restrict__ lin,
+                                              float* __restrict__ wet, int wr, const double* __restrict__ cring, int rc,
+                                              const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
                                               int64_t predelay, int64_t n_ref, int compat) {
     const int t = blockIdx.x, m = threadIdx.x;
     const int64_t i = (int64_t)t * MC_B + m;
-    const int64_t tau = tabs0 * MC_B + i;
+    const int64_t tau0 = tabs0 * MC_B;
+    const int64_t tau = tau0 + i;
     const int64_t u = tau - predelay;
+    // this thread's own sample goes to the wet ring (history for later batches / periods)
+    const float2 own = batch_wet(seg, sr, seg0, lin, T, t, m);
+    wet[(size_t)(tau & (wr - 1))] = own.x;
+    wet[(size_t)wr + (tau & (wr - 1))] = own.y;
     float wl = 0.f, wr_ = 0.f;
-    if (u >= 0) {
+    if (u >= tau0) {  // delayed sample lies in this batch: not in the ring yet
+        const int64_t j = u - tau0;
+        const float2 w = (j == i) ? own : batch_wet(seg, sr, seg0, lin, T, (int)(j >> 8), (int)(j & 255));
+        wl = w.x;
+        wr_ = w.y;
+    } else if (u >= 0) {
         wl = wet[(size_t)(u & (wr - 1))];
         wr_ = wet[(size_t)wr + (u & (wr - 1))];
     }
@@ -535,10 +556,10 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ wet, int
         const int64_t thi = u >> 8;
         const int64_t v = tau - n_ref;
         const int64_t tlo = v >= 0 ? (v >> 8) : -1;
-        const double* a = cring + (size_t)(thi % rc) * 4;
+        const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
         double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
         if (tlo >= 0) {
-            const double* b = cring + (size_t)(tlo % rc) * 4;
+            const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
             d0 -= b[0];
             d1 -= b[1];
             q0 -= b[2];
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         const float sc = 1.0f / FFT_N;
         const float2 lo = s_fft[m], hi = s_fft[MC_B + m];
         float* cur = seg + (size_t)seg0 * 2 * FFT_N;
-        const float* prv = seg + (size_t)((seg0 + sr - 1) % sr) * 2 * FFT_N;
+        const float* prv = seg + (size_t)((seg0 + sr - 1) & (sr - 1)) * 2 * FFT_N;
         const float wl = lo.x * sc + prv[MC_B + m], wr_ = lo.y * sc + prv[FFT_N + MC_B + m];
         cur[m] = lo.x * sc;
         cur[MC_B + m] = hi.x * sc;
@@ -703,8 +724,8 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         if (m == 0) {
             double d[4] = {0, 0, 0, 0};
             if (compat) corr_terms(s_sa, bp, irs, inv_n, d);
-            const double* pb = cring + (size_t)((tabs0 + rc - 1) % rc) * 4;
-            double* o = cring + (size_t)(tabs0 % rc) * 4;
+            const double* pb = cring + (size_t)((tabs0 + rc - 1) & (rc - 1)) * 4;
+            double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
             for (int c = 0; c < 4; c++) {
                 const double vv = (tabs0 > 0 ? pb[c] : 0.0) + d[c];
                 o[c] = vv;
@@ -736,11 +757,11 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             if (thi == tabs0) {
                 for (int c = 0; c < 4; c++) a[c] = s_c[c];
             } else {
-                const double* pa = cring + (size_t)(thi % rc) * 4;
+                const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
                 for (int c = 0; c < 4; c++) a[c] = pa[c];
             }
             if (tlo >= 0) {
-                const double* b = cring + (size_t)(tlo % rc) * 4;
+                const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
                 for (int c = 0; c < 4; c++) a[c] -= b[c];
             }
             const double sg = (u & 1) ? -1.0 : 1.0;

@@ -68,6 +68,8 @@ struct mc_engine {
     mc_config cfg;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side = nullptr;  // Q1/Q2 prefix sums run here, concurrently with the MAC
+    hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_corr[2] = {nullptr, nullptr};
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
     int stream_threshold = 0;
     int stream_nt = 256;
@@ -156,6 +158,7 @@ int drain_kernel_events(mc_engine* e) {
 }
 
 int zero_state(mc_engine* e) {
+    if (e->side) HIP_TRY(hipStreamSynchronize(e->side));
     HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_slotpan, 0, sizeof(float4) * (size_t)e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
@@ -338,11 +341,16 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
     const int seg0 = (int)(e->t_front % (uint64_t)e->sr);
-    const int64_t tau0 = (int64_t)e->t_front * MC_B;
 
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotpan, e->d_tw);
+    // Q1/Q2 prefix sums need only k_fwd's block sums: fork them to the side stream so they run beside the MAC
+    HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
+    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->side, d_sums, d_ptab, pstride, T, st.ctx.irs,
+                       1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)st.ctx.t0);
+    HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], e->side));
 
     int p_begin, p_end;
     partition_range(e, ir0, ir1, &p_begin, &p_end);
@@ -399,7 +407,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // K3, K4
     hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, stt, nsum, T, e->d_seg,
                        e->sr, seg0, e->d_tw);
-    hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, e->d_wet, e->wr, tau0, lin);
+    if (lin) hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, lin);
     HIP_TRY(hipGetLastError());
     e->pipe_count++;
     e->batch_seq++;
@@ -416,14 +424,13 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
     if (ctx.T != T) return fail(MC_ERR_ARG, "finish of %d blocks but the pending batch has %d", T, ctx.T);
     e->pipe_head = (e->pipe_head + 1) % kPipe;
     e->pipe_count--;
+    // join the side stream (Q1/Q2 prefix sums of this batch) — also when retiring without output, so that
+    // the batch's parameter slot is never rewritten while the side stream still reads it
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_corr[ctx.slot], 0));
     if (d_outL && d_outR) {
-        const int64_t tau0 = (int64_t)ctx.t0 * MC_B;
         const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
-        const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
-        if (lin_sum) hipLaunchKernelGGL(k_lin2ring, dim3(T), dim3(256), 0, e->stream, lin_sum, T, e->d_wet, e->wr, tau0);
-        hipLaunchKernelGGL(k_corr, dim3(1), dim3(256), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.irs,
-                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0);
-        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride,
+        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 % (uint64_t)e->sr), lin_sum,
+                           e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride,
                            d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref,
                            (int)e->cfg.compat);
         HIP_TRY(hipGetLastError());
@@ -593,9 +600,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->Pcap = cfg->max_partitions ? (int)cfg->max_partitions : (int)((cfg->n_ref - 1024 + MC_B - 1) / MC_B);
     e->Pstride = (int)next_pow2((uint64_t)round_up(e->Pcap, 16));
     e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tmax + 16);
-    e->sr = e->Tmax + 2;
+    e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
-    e->rc = (int)(cfg->n_ref / MC_B) + e->Tmax + 64;
+    e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 32;
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
@@ -612,6 +619,11 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     } while (0)
 
     ENG_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    ENG_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        ENG_TRY(hipEventCreateWithFlags(&e->ev_fwd[i], hipEventDisableTiming));
+        ENG_TRY(hipEventCreateWithFlags(&e->ev_corr[i], hipEventDisableTiming));
+    }
     e->stream = e->own_stream;
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotpan, sizeof(float4) * (size_t)e->ring));
@@ -683,6 +695,14 @@ void mc_destroy(mc_engine* e) {
             (void)hipEventDestroy(e->kev[i][0]);
             (void)hipEventDestroy(e->kev[i][1]);
         }
+    for (int i = 0; i < 2; i++) {
+        if (e->ev_fwd[i]) (void)hipEventDestroy(e->ev_fwd[i]);
+        if (e->ev_corr[i]) (void)hipEventDestroy(e->ev_corr[i]);
+    }
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        (void)hipStreamDestroy(e->side);
+    }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }

@@ -17,7 +17,8 @@ def main(tag, mode, dominant):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{mode}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+    ks = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     shutil.copy(ks, os.path.join(dst, f"{tag}_{mode}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(ks)))
     pmc = {}
@@ -26,7 +27,7 @@ def main(tag, mode, dominant):
         if not files:
             continue
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
             if r["Counter_Name"] == ctr:
                 agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
         pmc[ctr] = {k: sum(v) / len(v) for k, v in agg.items()}

@@ -373,3 +373,75 @@ def test_speculative_sweep_is_invisible(gpu_lib):
     a, bb = run(False), run(True)
     assert np.abs(a).max() > 0.01
     assert rms(a - bb) < 1e-7
+
+
+@pytest.mark.parametrize("taps,n_ref", [(441000, 524288), (1323000, 2097152)], ids=["10s_P1723", "30s_P5168"])
+def test_full_length_impulse_response(gpu_lib, taps, n_ref):
+    """Size-independent property at BASELINE sizes (configs 3 and 5 shapes, true-stereo 2x2 IR matrix):
+    a unit impulse on input 1 resp. input 2 returns the selected IR's L/R taps, scaled by the cold-start
+    cross-fade coefficient wet/5 (Q7, conv.cu:27), over every one of the P partitions.  compat=0 (linear)."""
+    from cuda_audio_amd.synth import make_ir
+
+    P = (taps + 255) // 256
+    nb = P + 3
+    irs = [make_ir(taps, seed=5678), make_ir(taps, seed=5680)]
+    c = _conv(fftSize=n_ref, max_batch=512, compat=False)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+    assert c.ir_info(0)["partitions"] == P
+    for h in (0, 1):
+        c.cc[h].value.update(select=h, dry=0.0, wet=1.0, level=1.0, panWet=0.0, vsteps=0)
+    for inp in (0, 1):
+        c.reset()
+        x = np.zeros((2, nb * 256), np.float32)
+        x[inp, 5] = 1.0
+        y = c.process(x[0], x[1])
+        want = np.zeros((2, nb * 256))
+        want[:, 5 : 5 + taps] = 0.2 * irs[inp].T.astype(np.float64)  # e(0) = wet / 5
+        err = np.abs(y - want).max()
+        assert err < 2e-6, f"input {inp}: max err {err:.3e} (IR peak {np.abs(irs[inp]).max():.3e})"
+        # the tail partitions really carry signal
+        assert np.abs(y[:, (P - 2) * 256 :]).max() > 1e-7
+    c.close()
+
+
+def test_config4_eight_channels_sharded(oracle_mod, gpu_lib):
+    """BASELINE config 4 shape: 8 channels = 4 stereo `Convolution` pairs (main.cu:31-39 makes one object per
+    pair), each with IR partitions sharded over G engines whose partial blocks are summed.  One GPU, virtual
+    shards; checked per pair against the oracle."""
+    import torch
+
+    from cuda_audio_amd.sharded import shard_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, T, n_ref, G = 64, 32, 32768, 4
+    dev = torch.device("cuda:0")
+    for pair in range(4):
+        x = make_input(nb * 256, seed=100 + 10 * pair)
+        ir = make_ir(25000, seed=40 + pair, norm=0.02)  # 98 partitions
+        o = oracle_mod.Upols(n_ref, True)
+        o.prepare(0, ir)
+        want = o.process(x[0], x[1])
+        bounds = [shard_bounds(98, G, g) for g in range(G)]
+        shards = [_conv(fftSize=n_ref, max_batch=T, part_begin=a, part_end=b) for a, b in bounds if b > a]
+        for s in shards:
+            s.prepare(0, ir)
+        got = np.zeros_like(want)
+        xin = torch.from_numpy(x).to(dev)
+        for k in range(nb // T):
+            sl = xin[:, k * T * 256 : (k + 1) * T * 256]
+            parts = [torch.zeros(2 * T * 256, device=dev) for _ in shards]
+            for s, p in zip(shards, parts):
+                s.partial_device(sl[0].data_ptr(), sl[1].data_ptr(), p.data_ptr(), T)
+                s.sync()
+            total = torch.stack(parts).sum(0)
+            out = torch.zeros(2, T * 256, device=dev)
+            shards[0].finish_device(sl[0].data_ptr(), sl[1].data_ptr(), total.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), T)
+            shards[0].sync()
+            for s in shards[1:]:
+                s.finish_device(None, None, None, None, None, T)
+            got[:, k * T * 256 : (k + 1) * T * 256] = out.cpu().numpy()
+        for s in shards:
+            s.close()
+        err = rms(got - want)
+        assert err <= RMS_TOL, f"pair {pair}: rms {err:.3e}"
