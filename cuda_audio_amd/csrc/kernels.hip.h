@@ -521,6 +521,78 @@ __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sum
 }
 
 // ---------------------------------------------------------------------------
+// Q8: the reference adds block t's N_ref-long contribution w_t[s] to its
+// accumulator at s + predelay and discards what falls past N_ref
+// (f_pointwiseAdd loops s < N, conv.cu:94-98).  For IRs and predelays with
+// taps + 255 + predelay > N_ref that cuts real signal: every output sample tau
+// loses  sum_{t: 256 t <= tau - N_ref} w_t[tau - predelay - 256 t].  The lost
+// terms are recomputed here in the time domain (a 256-term dot product per
+// affected block and path) and subtracted before the clamp; the host enables
+// the pass only in that regime.  Needs the input history (ring), the gains of
+// past blocks (ring) and the time-domain IRs.
+// ---------------------------------------------------------------------------
+struct TailDrop {
+    int on;
+    const float2* h0;  // time-domain taps {L, R} of the IR selected by half 0 (input 1)
+    const float2* h1;  // ... half 1 (input 2)
+    int L0, L1;        // taps
+    float* xhist;      // [2][xr] input history ring (absolute sample index mod xr)
+    int xr;
+    float4* gring;     // [rc] wet gains {L<-in1, L<-in2, R<-in1, R<-in2} of past blocks
+};
+
+__device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
+                                          const BlockParams* __restrict__ ptab, int pstride, int rc,
+                                          const float* __restrict__ cur1, const float* __restrict__ cur2, float& dl,
+                                          float& dr) {
+    dl = dr = 0.f;
+    const int64_t v = tau - n_ref;
+    if (v < 0) return;
+    const int lmax = max(td.L0, td.L1);
+    const int64_t hi_tb = v >> 8;
+    int64_t lo = tau - pd - 254 - lmax;
+    int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
+    for (int64_t tb = lo_tb; tb <= hi_tb; tb++) {
+        const int64_t s = tau - pd - (tb << 8);  // position inside block tb's contribution, >= n_ref - pd
+        float4 g;
+        const int64_t rel = tb - (tau0 >> 8);
+        if (rel >= 0 && rel < T) {
+            const BlockParams& bp = ptab[rel * pstride];
+            g = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
+        } else {
+            g = td.gring[(size_t)(tb & (rc - 1))];
+        }
+        float aL0 = 0.f, aR0 = 0.f, aL1 = 0.f, aR1 = 0.f;
+        const int64_t base = tb << 8;
+        for (int m = 0; m < MC_B; m++) {
+            const int64_t j = s - m;
+            if (j < 0) break;
+            const int64_t sig = base + m;
+            float x1, x2;
+            if (sig >= tau0) {
+                x1 = cur1[sig - tau0];
+                x2 = cur2[sig - tau0];
+            } else {
+                x1 = td.xhist[(size_t)(sig & (td.xr - 1))];
+                x2 = td.xhist[(size_t)td.xr + (sig & (td.xr - 1))];
+            }
+            if (j < td.L0) {
+                const float2 h = td.h0[j];
+                aL0 = fmaf(x1, h.x, aL0);
+                aR0 = fmaf(x1, h.y, aR0);
+            }
+            if (j < td.L1) {
+                const float2 h = td.h1[j];
+                aL1 = fmaf(x2, h.x, aL1);
+                aR1 = fmaf(x2, h.y, aR1);
+            }
+        }
+        dl += g.x * aL0 + g.y * aL1;
+        dr += g.z * aR0 + g.w * aR1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K6: predelay + Q1/Q2 window sums + saturating clamp + dry mix
 // (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
 // conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
@@ -530,7 +602,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
-                                              int64_t predelay, int64_t n_ref, int compat) {
+                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td) {
     const int t = blockIdx.x, m = threadIdx.x;
     const int64_t i = (int64_t)t * MC_B + m;
     const int64_t tau0 = tabs0 * MC_B;
@@ -571,6 +643,16 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     }
     const BlockParams& bp = ptab[(int64_t)t * pstride];
     const float x1 = in1[i], x2 = in2[i];
+    // history for later calls: input samples and this block's wet gains (Q8 pass)
+    td.xhist[(size_t)(tau & (td.xr - 1))] = x1;
+    td.xhist[(size_t)td.xr + (tau & (td.xr - 1))] = x2;
+    if (m == 0) td.gring[(size_t)((tabs0 + t) & (rc - 1))] = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
+    if (td.on) {
+        float dl, dr;
+        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr);
+        wl -= dl;
+        wr_ -= dr;
+    }
     float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
     float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
     outL[i] = vl + x1 * bp.d[0] + x2 * bp.d[1];
@@ -598,7 +680,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                                                int seg0, float* __restrict__ wet, int wr, double* __restrict__ cring,
                                                int rc, IrSums irs, double inv_n, int compat, int64_t tabs0,
                                                int64_t predelay, int64_t n_ref, float* __restrict__ outL,
-                                               float* __restrict__ outR, const float2* __restrict__ g_tw) {
+                                               float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
     __shared__ float4 s_x[MC_NB];   // scaled spectra of the new block {X1, X2}
@@ -769,6 +851,15 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             cr = a[1] + sg * a[3];
         }
         const float x1 = s_in[0][m], x2 = s_in[1][m];
+        td.xhist[(size_t)(tau & (td.xr - 1))] = x1;
+        td.xhist[(size_t)td.xr + (tau & (td.xr - 1))] = x2;
+        if (m == 0) td.gring[(size_t)(tabs0 & (rc - 1))] = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
+        if (td.on) {
+            float dl, dr;
+            tail_drop(td, tau, tabs0 * MC_B, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr);
+            wl -= dl;
+            wr_ -= dr;
+        }
         const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
         outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];

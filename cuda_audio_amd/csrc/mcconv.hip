@@ -57,6 +57,7 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 
 struct IrEntry {
     float4* d_H = nullptr;
+    float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint64_t taps = 0;
     int P = 0;
     double sums[4] = {0, 0, 0, 0};
@@ -79,6 +80,9 @@ struct mc_engine {
     float4 *d_fdl = nullptr, *d_slotpan = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
     float *d_seg = nullptr, *d_wet = nullptr, *d_lin = nullptr;
     double* d_cring = nullptr;
+    float* d_xhist = nullptr;   // [2][xr] input history (Q8 pass)
+    float4* d_gring = nullptr;  // [rc] wet gains of past blocks (Q8 pass)
+    int xr = 0;
     BlockParams* d_ptab = nullptr;
     float2* d_tw = nullptr;
     float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // in1, in2, outL, outR staging for host-pointer calls
@@ -106,6 +110,7 @@ struct mc_engine {
         uint64_t predelay = 0;
         IrSums irs;
         int slot = 0;
+        uint64_t sel[2] = {0, 0};
     } pipe[2];
     int pipe_head = 0, pipe_count = 0;
     uint64_t batch_seq = 0;
@@ -164,6 +169,8 @@ int zero_state(mc_engine* e) {
     HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_wet, 0, sizeof(float) * 2 * (size_t)e->wr, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_cring, 0, sizeof(double) * 4 * (size_t)e->rc, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_xhist, 0, sizeof(float) * 2 * (size_t)e->xr, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_gring, 0, sizeof(float4) * (size_t)e->rc, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->e[0] = e->e[1] = 0.0;
     e->t_abs = e->t_front = 0;
@@ -285,6 +292,8 @@ int stage_params(mc_engine* e, int T, Staged* st) {
     st->ctx.pstride = pstride;
     st->ctx.predelay = cc[0].predelay;
     st->ctx.slot = bslot;
+    st->ctx.sel[0] = cc[0].select;
+    st->ctx.sel[1] = cc[1].select;
     for (int c = 0; c < 2; c++) {
         st->ctx.irs.sig[0][c] = ir0.sums[c];
         st->ctx.irs.sig[1][c] = ir1.sums[c];
@@ -292,6 +301,21 @@ int stage_params(mc_engine* e, int T, Staged* st) {
         st->ctx.irs.alp[1][c] = ir1.sums[2 + c];
     }
     return MC_OK;
+}
+
+// Q8 pass descriptor: enabled only when some contribution is shifted past n_ref by the predelay
+TailDrop make_taildrop(const mc_engine* e, const IrEntry& ir0, const IrEntry& ir1, uint64_t predelay) {
+    TailDrop td;
+    const uint64_t lmax = std::max(ir0.taps, ir1.taps);
+    td.on = (e->cfg.compat && lmax + 255 + predelay > e->cfg.n_ref) ? 1 : 0;
+    td.h0 = ir0.d_h;
+    td.h1 = ir1.d_h;
+    td.L0 = (int)ir0.taps;
+    td.L1 = (int)ir1.taps;
+    td.xhist = e->d_xhist;
+    td.xr = e->xr;
+    td.gring = e->d_gring;
+    return td;
 }
 
 // partition range [p_begin, p_end) this engine sweeps for the two selected IRs (multiples of 16)
@@ -432,7 +456,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 % (uint64_t)e->sr), lin_sum,
                            e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride,
                            d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref,
-                           (int)e->cfg.compat);
+                           (int)e->cfg.compat, make_taildrop(e, e->irs[ctx.sel[0]], e->irs[ctx.sel[1]], ctx.predelay));
         HIP_TRY(hipGetLastError());
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
@@ -500,7 +524,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                        e->Pstride, do_p0, e->d_fdl, e->d_slotpan, e->ring, slot0, e->d_part, e->nchunk, have_part, st.d_ptab,
                        e->d_seg, e->sr, seg0, e->d_wet, e->wr, e->d_cring, e->rc, st.ctx.irs, 1.0 / (double)e->cfg.n_ref,
                        (int)e->cfg.compat, (int64_t)e->t_front, (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref,
-                       e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw);
+                       e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw, make_taildrop(e, ir0, ir1, st.ctx.predelay));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
@@ -633,6 +657,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
+    e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B + MC_MAX_PREDELAY + 1024);
+    ENG_TRY(hipMalloc(&e->d_xhist, sizeof(float) * 2 * (size_t)e->xr));
+    ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)e->rc));
     ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
@@ -669,6 +696,8 @@ void mc_destroy(mc_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
+    for (int i = 0; i < kMaxIrs; i++)
+        if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     (void)hipFree(e->d_fdl);
     (void)hipFree(e->d_slotpan);
     (void)hipFree(e->d_Y);
@@ -677,6 +706,8 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_seg);
     (void)hipFree(e->d_wet);
     (void)hipFree(e->d_cring);
+    (void)hipFree(e->d_xhist);
+    (void)hipFree(e->d_gring);
     (void)hipFree(e->d_ptab);
     (void)hipFree(e->d_tw);
     for (int i = 0; i < 4; i++) (void)hipFree(e->d_io[i]);
@@ -736,8 +767,12 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
-    (void)hipFree(d_lr);
-    if (er != hipSuccess) return fail(MC_ERR_HIP, "IR preparation failed: %s", hipGetErrorString(er));
+    if (er != hipSuccess) {
+        (void)hipFree(d_lr);
+        return fail(MC_ERR_HIP, "IR preparation failed: %s", hipGetErrorString(er));
+    }
+    if (ir.d_h) (void)hipFree(ir.d_h);
+    ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
     double s[4] = {0, 0, 0, 0};
     for (uint64_t m = 0; m < n; m++) {
         const double sg = (m & 1) ? -1.0 : 1.0;

@@ -445,3 +445,44 @@ def test_config4_eight_channels_sharded(oracle_mod, gpu_lib):
             s.close()
         err = rms(got - want)
         assert err <= RMS_TOL, f"pair {pair}: rms {err:.3e}"
+
+
+@pytest.mark.parametrize("n_ref,taps,pd", [(4096, (2500, 3072), 1024), (4096, (3072, 3072), 2000), (16384, (15360, 9000), 8128)],
+                         ids=["default_predelay", "pd2000", "max_predelay"])
+@pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
+def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack):
+    """Q8: with taps + 255 + predelay > N_ref the reference discards what the predelay shifts past N_ref
+    (conv.cu:94-98).  The shipped defaults are in that regime (predelay 1024, IRs truncated to N-1024).
+    Slowly decaying IRs so that the discarded tail is far above the tolerance."""
+    from cuda_audio_amd.synth import make_input
+
+    nb = 3 * n_ref // 256 // 2 + 40
+    x = make_input(nb * 256)
+    rng = np.random.default_rng(5)
+    irs = []
+    for L in taps:
+        h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (2.0 * L))[:, None]
+        irs.append((h * np.sqrt(0.004 / L)).astype(np.float32))
+    p0, p1 = dict(BASE, predelay=pd), dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=37)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    want = ref.process(x[0], x[1])
+    if jack:
+        got = np.concatenate([np.stack(c.onProcess(x[0, b * 256:(b + 1) * 256], x[1, b * 256:(b + 1) * 256]))
+                              for b in range(nb)], axis=1)
+    else:
+        got = c.process(x[0], x[1])
+    # the discarded part is well above the bar: a linear engine would fail here
+    lin = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        lin.prepare(i, ir)
+    apply_params(lin, p0, p1, True)
+    assert rms(lin.process(x[0], x[1]) - want) > 5 * RMS_TOL
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
