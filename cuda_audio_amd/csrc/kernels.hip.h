@@ -3,13 +3,23 @@
 //
 // Data layout in HBM (all fp32; "bin" = one of 256 packed bins of a 512-point
 // real-signal spectrum, bin 0 packs {DC, Nyquist} which are both real):
-//   IR spectra   H[idx] : float4 [256 bins][Pstride]     {H_L.re, H_L.im, H_R.re, H_R.im}
-//   delay line   FDL    : float4 [256 bins][R slots]     {X_1.re, X_1.im, X_2.re, X_2.im} * s_i(t)
-//   MAC output   Y      : float4 [256 bins][Tcap]        {Y_L.re, Y_L.im, Y_R.re, Y_R.im}
-//   segments     seg    : float  [SR blocks][2 ch][512]  inverse transforms (overlap-add halves)
-//   wet ring     wet    : float  [2 ch][WR samples]      indexed by absolute sample mod WR
+//   IR spectra   H[idx]   : float4 [256 bins][Pstride]   {H_L.re, H_L.im, H_R.re, H_R.im}
+//   delay line   FDL      : float4 [256 bins][R slots]   {X_1.re, X_1.im, X_2.re, X_2.im}  (raw spectra)
+//   slot gains   gain[v]  : float4 [R slots]             {L<-in1, L<-in2, R<-in1, R<-in2} of voice v
+//   MAC output   Y        : float4 [256 bins][Tcap]      {Y_L.re, Y_L.im, Y_R.re, Y_R.im}
+//   segments     seg      : float  [SR blocks][2 ch][512] inverse transforms (overlap-add halves)
+//   wet ring     wet      : float  [2 ch][WR samples]    indexed by absolute sample mod WR
 // Bin-major layouts make the partition sum of one bin a contiguous stream that
 // one workgroup owns: no cross-workgroup reduction, coalesced 16-byte lanes.
+//
+// Gains.  In the reference every scalar that shapes the wet signal — pan
+// (conv.cu:386-389), level (:394), wet and the cross-fade state of the live
+// IR spectra (f_interpolate, :15-32) — multiplies the WHOLE contribution of the
+// input block at which it was current.  Here the delay line keeps raw spectra
+// and each slot carries its four path gains; a "voice" is one pair of IRs
+// (one per input) with its own gain table.  Normally one voice is active; after
+// a select CC the outgoing IR and the incoming IR are two voices whose
+// coefficients follow the reference's recurrence exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,33 +29,38 @@
 #define MC_B 256
 #define MC_K 512
 #define MC_NB 256
+#define MC_MAXV 3    // voices (IR pairs) that may sound at once
 #define FWD_TILE 8   // blocks per workgroup of the forward / inverse transform kernels (2 per wave)
 #define FWD_TILE_LOG2 3
 
-// Per-block parameters computed on the host in double (Q7 ramp, pans, levels)
+// Per-block parameters computed on the host in double (cross-fade recurrence, pans, levels)
 struct BlockParams {
-    double G[4];    // wet gain of path c*2+i attached to this input block: pan_c(panWet_i) level_i e_i(t)
-    float s[2];     // level_i * e_i(t): scale of input i's spectrum in the delay line
-    float pad0[2];
-    float d[4];     // dry gain c*2+i: dry_i pan_c(panDry_i) level_i      (conv.cu:418-427)
-    float pan[4];   // pan_c(panWet_i), c*2+i                              (conv.cu:386-389)
+    double G[MC_MAXV][4];  // wet gain of voice v, path c*2+i, attached to this input block
+    float g[MC_MAXV][4];   // the same in float: the slot's entry of the gain tables
+    float d[4];            // dry gain c*2+i: dry_i pan_c(panDry_i) level_i      (conv.cu:418-427)
+};
+
+// IR sums of the voices' IRs: sig = sum h, alp = sum h (-1)^m; [voice][half][L/R]
+struct VoiceSums {
+    double sig[MC_MAXV][2][2];
+    double alp[MC_MAXV][2][2];
 };
 
 // ---------------------------------------------------------------------------
-// K1: forward transform of T input blocks -> delay-line slots.
+// K1: forward transform of T input blocks -> delay-line slots (raw spectra).
 // Replaces f_pack2R2C + memset + cufftExecC2C + f_unpackC22R (conv.cu:35-73,
 // 321-328, 367-371) for one zero-padded 256-frame block per wave pass.  The
 // same kernel prepares IR partitions (conv.cu:207-253): the IR's L/R channels
-// are the two "inputs", slot = partition index, unit scale.
+// are the two "inputs", slot = partition index.
 // grid = ceil(T / 8), block = 256 (4 waves x 2 transforms each).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
-                                             int in_stride,  // floats between successive frames (1, or 2 for interleaved IR)
+                                             int in_stride,     // floats between successive frames (1, or 2 for interleaved IR)
                                              int64_t n_frames,  // valid frames in in1/in2 (zero beyond)
                                              int T, float4* __restrict__ fdl, int ring, int slot0,
                                              const BlockParams* __restrict__ ptab, int pstride,
-                                             float4* __restrict__ sums,  // [T] raw {S1,S2,A1,A2} or null
-                                             float4* __restrict__ slotpan,  // [ring] or null
+                                             float4* __restrict__ sums,      // [T] raw {S1,S2,A1,A2} or null
+                                             float4* __restrict__ slotgain,  // [MC_MAXV][ring] or null
                                              const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
@@ -70,11 +85,6 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
         }
         fft512_wave<-1>(v, lds, s_tw, lane);
         if (t < T) {
-            float s1 = 1.f, s2 = 1.f;
-            if (ptab) {
-                s1 = ptab[(int64_t)t * pstride].s[0];
-                s2 = ptab[(int64_t)t * pstride].s[1];
-            }
             // two-for-one split of the packed transform (true spectra; the
             // reference's DC/Nyquist shortcuts Q1/Q2 are rank-1 terms added in k_post)
 #pragma unroll
@@ -86,16 +96,16 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
                     float2 zn = lds[MC_B];
                     x1 = make_float2(za.x, zn.x);  // {DC, Nyquist} of input 1
                     x2 = make_float2(za.y, zn.y);  // {DC, Nyquist} of input 2
-                    if (sums) sums[t] = make_float4(za.x, za.y, zn.x, zn.y);  // S1, S2, A1, A2 (unscaled)
+                    if (sums) sums[t] = make_float4(za.x, za.y, zn.x, zn.y);  // S1, S2, A1, A2
                 } else {
                     x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
                     x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
                 }
-                s_tile[k][tb] = make_float4(x1.x * s1, x1.y * s1, x2.x * s2, x2.y * s2);
+                s_tile[k][tb] = make_float4(x1.x, x1.y, x2.x, x2.y);
             }
-            if (slotpan && lane == 0) {
-                const float* pn = ptab[(int64_t)t * pstride].pan;
-                slotpan[(slot0 + t) & (ring - 1)] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+            if (slotgain && lane < MC_MAXV) {
+                const float* gv = ptab[(int64_t)t * pstride].g[lane];
+                slotgain[(size_t)lane * ring + ((slot0 + t) & (ring - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
             }
         }
         __syncthreads();  // lds reused by the next transform
@@ -136,6 +146,13 @@ __device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, 
 // window is conflict-free, and each window entry is reused for 4 outputs from
 // registers.  The 4 waves split the partition range; partial sums meet in LDS.
 // grid = 256 bins x ceil(T/256); block ids with equal bin share an XCD (id % 8).
+//
+// SLOTGAIN = false: every slot in the window carries the same four gains (the
+//   steady state): the window holds raw spectra, four path sums are kept and the
+//   gains are applied once at the end.
+// SLOTGAIN = true : gains differ between slots (cold-start ramp, a parameter
+//   or IR change within the last P blocks): the window is filled with the
+//   per-path products gain(slot) * X, two windows {L paths, R paths}.
 // ---------------------------------------------------------------------------
 #define MAC_PSEG 1024                       // partitions per LDS window segment
 #define MAC_WQ ((MAC_PSEG + 256 + 16) / 4)  // quarter-window length (entries), incl. prefetch slack
@@ -143,10 +160,6 @@ __device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One wave's share of a window segment: partitions pse-1-q for q in [q_lo, q_hi).
-// Software-pipelined one iteration (4 partitions) ahead: the 64-byte scalar
-// loads of the next 4 partitions' spectra and the 4 ds_read_b128 of the next
-// window entries are issued before the 128 packed FMAs of the current step, so
-// the s_waitcnt at the top of the next iteration finds them complete.
 template <bool PACKED>
 __device__ __forceinline__ void mac_sweep(const float4* __restrict__ H0k, const float4* __restrict__ H1k, int pse,
                                           int q_lo, int q_hi, const float4* s_win, int lane, float2 (&acc)[4][4]) {
@@ -161,7 +174,6 @@ __device__ __forceinline__ void mac_sweep(const float4* __restrict__ H0k, const 
     f32x16 hc0 = *reinterpret_cast<const f32x16*>(H0k + (pse - 4 - q_lo));
     f32x16 hc1 = *reinterpret_cast<const f32x16*>(H1k + (pse - 4 - q_lo));
     for (int q = q_lo; q < q_hi; q += 4) {
-        // prefetch for iteration q + 4 (clamped on the last one: loads stay in range, values unused)
         const int qn = min(q + 4, q_hi - 4);
         const f32x16 hn0 = *reinterpret_cast<const f32x16*>(H0k + (pse - 4 - qn));
         const f32x16 hn1 = *reinterpret_cast<const f32x16*>(H1k + (pse - 4 - qn));
@@ -191,13 +203,55 @@ __device__ __forceinline__ void mac_sweep(const float4* __restrict__ H0k, const 
     }
 }
 
+// the same sweep over gain-scaled windows: wl = {gL0 X1, gL1 X2}, wr = {gR0 X1, gR1 X2}
+template <bool PACKED>
+__device__ __forceinline__ void mac_sweep_g(const float4* __restrict__ H0k, const float4* __restrict__ H1k, int pse,
+                                            int q_lo, int q_hi, const float4* s_wl, const float4* s_wr, int lane,
+                                            float2 (&acc)[4][2]) {
+    float4 wl[8], wr[8];
+    const int b0 = lane + (q_lo >> 2);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        wl[u] = s_wl[b0 + u * MAC_WQ];
+        wr[u] = s_wr[b0 + u * MAC_WQ];
+        wl[4 + u] = s_wl[b0 + u * MAC_WQ + 1];
+        wr[4 + u] = s_wr[b0 + u * MAC_WQ + 1];
+    }
+    for (int q = q_lo; q < q_hi; q += 4) {
+        const f32x16 hc0 = *reinterpret_cast<const f32x16*>(H0k + (pse - 4 - q));
+        const f32x16 hc1 = *reinterpret_cast<const f32x16*>(H1k + (pse - 4 - q));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int o = 4 * (3 - u);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 xl = wl[u + r], xr = wr[u + r];
+                cmac<PACKED>(acc[r][0], hc0[o + 0], hc0[o + 1], xl.x, xl.y);
+                cmac<PACKED>(acc[r][0], hc1[o + 0], hc1[o + 1], xl.z, xl.w);
+                cmac<PACKED>(acc[r][1], hc0[o + 2], hc0[o + 3], xr.x, xr.y);
+                cmac<PACKED>(acc[r][1], hc1[o + 2], hc1[o + 3], xr.z, xr.w);
+            }
+        }
+        const int bn = lane + (q >> 2) + 2;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            wl[u] = wl[4 + u];
+            wr[u] = wr[4 + u];
+            wl[4 + u] = s_wl[bn + u * MAC_WQ];
+            wr[4 + u] = s_wr[bn + u * MAC_WQ];
+        }
+    }
+}
+
+template <bool SLOTGAIN>
 __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__ H0, const float4* __restrict__ H1,
-                                                      int pstride_ir,  // slots per bin of the IR arrays
+                                                      int pstride_ir,          // slots per bin of the IR arrays
                                                       int p_begin, int p_end,  // partition range, multiples of 16
                                                       const float4* __restrict__ fdl, int ring, int slot0, int T,
-                                                      float4 pan,  // pan_c(panWet_i): {L0, L1, R0, R1}
-                                                      float4* __restrict__ Y, int tcap) {
-    __shared__ float4 s_win[4 * MAC_WQ];
+                                                      float4 ugain,                         // SLOTGAIN = false
+                                                      const float4* __restrict__ slotgain,  // SLOTGAIN = true: [ring]
+                                                      float4* __restrict__ Y, int tcap, int accumulate) {
+    __shared__ float4 s_win[(SLOTGAIN ? 8 : 4) * MAC_WQ];
     const int bin = blockIdx.x & (MC_NB - 1);
     const int tile = blockIdx.x >> 8;
     const int t0 = tile * 256;
@@ -207,11 +261,14 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
     const float4* H1k = H1 + (size_t)bin * pstride_ir;
     const float4* fk = fdl + (size_t)bin * ring;
 
-    float2 acc[4][4];
+    float2 acc[4][4];   // SLOTGAIN = false: four path sums per output
+    float2 accg[4][2];  // SLOTGAIN = true : Y_L, Y_R per output
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[r][c] = make_float2(0.f, 0.f);
+        accg[r][0] = accg[r][1] = make_float2(0.f, 0.f);
+    }
 
     for (int ps = p_begin; ps < p_end; ps += MAC_PSEG) {
         const int pse = min(ps + MAC_PSEG, p_end);
@@ -222,24 +279,46 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
         __syncthreads();  // previous segment's readers are done
         for (int e = threadIdx.x; e < nwin + 12; e += 256) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < nwin) x = fk[(sbase + e) & (ring - 1)];
-            s_win[(e & 3) * MAC_WQ + (e >> 2)] = x;
+            const int slot = (sbase + e) & (ring - 1);
+            if (e < nwin) x = fk[slot];
+            const int pos = (e & 3) * MAC_WQ + (e >> 2);
+            if (SLOTGAIN) {
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < nwin) g = slotgain[slot];
+                s_win[pos] = make_float4(g.x * x.x, g.x * x.y, g.y * x.z, g.y * x.w);
+                s_win[4 * MAC_WQ + pos] = make_float4(g.z * x.x, g.z * x.y, g.w * x.z, g.w * x.w);
+            } else {
+                s_win[pos] = x;
+            }
         }
         __syncthreads();
         const int per = seg >> 2;  // partitions per wave, multiple of 4
         const int q_lo = wave * per, q_hi = q_lo + per;
-        if (bin == 0)
-            mac_sweep<true>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
-        else
-            mac_sweep<false>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
+        if (SLOTGAIN) {
+            if (bin == 0)
+                mac_sweep_g<true>(H0k, H1k, pse, q_lo, q_hi, s_win, s_win + 4 * MAC_WQ, lane, accg);
+            else
+                mac_sweep_g<false>(H0k, H1k, pse, q_lo, q_hi, s_win, s_win + 4 * MAC_WQ, lane, accg);
+        } else {
+            if (bin == 0)
+                mac_sweep<true>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
+            else
+                mac_sweep<false>(H0k, H1k, pse, q_lo, q_hi, s_win, lane, acc);
+        }
     }
-    // apply the (batch-uniform) wet pans, then sum the 4 waves' partials in LDS
+    // sum the 4 waves' partials in LDS (uniform gains applied here)
     __syncthreads();
     float* red = reinterpret_cast<float*>(s_win);  // [wave][16][64]
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        float2 yl = make_float2(pan.x * acc[r][0].x + pan.y * acc[r][1].x, pan.x * acc[r][0].y + pan.y * acc[r][1].y);
-        float2 yr = make_float2(pan.z * acc[r][2].x + pan.w * acc[r][3].x, pan.z * acc[r][2].y + pan.w * acc[r][3].y);
+        float2 yl, yr;
+        if (SLOTGAIN) {
+            yl = accg[r][0];
+            yr = accg[r][1];
+        } else {
+            yl = make_float2(ugain.x * acc[r][0].x + ugain.y * acc[r][1].x, ugain.x * acc[r][0].y + ugain.y * acc[r][1].y);
+            yr = make_float2(ugain.z * acc[r][2].x + ugain.w * acc[r][3].x, ugain.z * acc[r][2].y + ugain.w * acc[r][3].y);
+        }
         red[(wave * 16 + r * 4 + 0) * 64 + lane] = yl.x;
         red[(wave * 16 + r * 4 + 1) * 64 + lane] = yl.y;
         red[(wave * 16 + r * 4 + 2) * 64 + lane] = yr.x;
@@ -257,25 +336,36 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
             for (int w = 0; w < 4; w++) s += red[(w * 16 + r * 4 + c) * 64 + j];
             f[c] = s;
         }
-        if (t0 + o < T) Y[(size_t)bin * tcap + t0 + o] = make_float4(f[0], f[1], f[2], f[3]);
+        if (t0 + o < T) {
+            float4* dst = Y + (size_t)bin * tcap + t0 + o;
+            if (accumulate) {  // a further voice adds to what the first one wrote
+                const float4 y = *dst;
+                f[0] += y.x;
+                f[1] += y.y;
+                f[2] += y.z;
+                f[3] += y.w;
+            }
+            *dst = make_float4(f[0], f[1], f[2], f[3]);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // K2 (stream): the same sum as a bandwidth-bound reduction, for single blocks
 // (the JACK path) and short batches.  Lanes = partitions: each lane loads 16 B
-// of each IR and 16 B of the delay line per partition (coalesced), the pan of
-// the slot's input block is applied per term (exact for time-varying pans).
-// grid = (256 bins, nchunk, T); partial sums per chunk are added by k_inv.
+// of each IR and 16 B of the delay line per partition (coalesced) plus the
+// slot's gains (or one uniform set).  All loads of STREAM_U partitions are
+// issued before the first use.  grid = (256 bins, nchunk, T); partial sums per
+// chunk (and voice) are added by k_inv / k_tail1.
 // ---------------------------------------------------------------------------
-#define STREAM_U 4  // partitions per lane and loop trip, all loads issued before the first use
+#define STREAM_U 4  // partitions per lane and loop trip
 
-template <bool UNIFORM_PAN, int NT>
+template <bool UNIFORM, int NT>
 __global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0, const float4* __restrict__ H1,
-                                                    int pstride_ir, int p_begin, int p_end, int chunk,
-                                                    const float4* __restrict__ fdl, const float4* __restrict__ slotpan,
-                                                    int ring, int slot0, float4* __restrict__ part, int nchunk,
-                                                    float4 upan) {
+                                                   int pstride_ir, int p_begin, int p_end, int chunk,
+                                                   const float4* __restrict__ fdl, const float4* __restrict__ slotgain,
+                                                   int ring, int slot0, float4* __restrict__ part, int nsum, int ch_off,
+                                                   float4 ugain) {
     const int bin = blockIdx.x, ch = blockIdx.y, t = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* H0k = H0 + (size_t)bin * pstride_ir;
@@ -292,8 +382,8 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0
             const int p = min(p0 + NT * u, hi - 1);  // clamped: the load is always in range, masked below
             const int slot = (st - p) & (ring - 1);
             x[u] = fk[slot];
-            g[u] = upan;  // pans unchanged over the whole window: one value for every slot
-            if (!UNIFORM_PAN) g[u] = slotpan[slot];
+            g[u] = ugain;
+            if (!UNIFORM) g[u] = slotgain[slot];
             h0[u] = H0k[p];
             h1[u] = H1k[p];
         }
@@ -319,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0
             }
         }
     }
-    // wavefront butterfly reduction (64 lanes), then 4 waves through LDS
+    // wavefront butterfly reduction (64 lanes), then the waves through LDS
     float v[4] = {yl.x, yl.y, yr.x, yr.y};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -341,7 +431,7 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0
             o.z += s_red[w][2];
             o.w += s_red[w][3];
         }
-        part[((size_t)t * MC_NB + bin) * nchunk + ch] = o;
+        part[((size_t)t * MC_NB + bin) * nsum + ch_off + ch] = o;
     }
 }
 
@@ -444,35 +534,32 @@ __global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int 
 
 // ---------------------------------------------------------------------------
 // K5: per-block rank-1 terms of the reference's DC / Nyquist quirks (Q1, Q2;
-// conv.cu:61 and :55-71) and their running prefix sums (float64 rings indexed
-// by absolute block).  One workgroup; T <= 256 * 16.
-//   D_L = -(G_L0 S2 sig_0R + G_L1 S2 sig_1L)/N   D_R = -(G_R0 S1 sig_0R + G_R1 S2 sig_1R)/N
-//   Q_c = -(G_c0 A1 alp_0c + G_c1 A2 alp_1c)/N
+// conv.cu:61 and :55-71) and their running prefix sums (float64 ring indexed
+// by absolute block).  With G = wet gain of a voice's path, sig/alp its IR sums:
+//   D_L = -sum_v (G_L0 S2 sig_0R + G_L1 S2 sig_1L)/N   D_R = -sum_v (G_R0 S1 sig_0R + G_R1 S2 sig_1R)/N
+//   Q_c = -sum_v (G_c0 A1 alp_0c + G_c1 A2 alp_1c)/N
 // ---------------------------------------------------------------------------
-struct IrSums {
-    double sig[2][2];  // [half][L/R]  sum h
-    double alp[2][2];  // [half][L/R]  sum h (-1)^m
-};
-
-__device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& bp, const IrSums& irs, double inv_n,
+__device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& bp, const VoiceSums& vs, double inv_n,
                                            double (&d)[4]) {
     const double S1 = sa.x, S2 = sa.y, A1 = sa.z, A2 = sa.w;
-    d[0] = -(bp.G[0] * S2 * irs.sig[0][1] + bp.G[1] * S2 * irs.sig[1][0]) * inv_n;
-    d[1] = -(bp.G[2] * S1 * irs.sig[0][1] + bp.G[3] * S2 * irs.sig[1][1]) * inv_n;
-    d[2] = -(bp.G[0] * A1 * irs.alp[0][0] + bp.G[1] * A2 * irs.alp[1][0]) * inv_n;
-    d[3] = -(bp.G[2] * A1 * irs.alp[0][1] + bp.G[3] * A2 * irs.alp[1][1]) * inv_n;
+    d[0] = d[1] = d[2] = d[3] = 0.0;
+#pragma unroll
+    for (int v = 0; v < MC_MAXV; v++) {
+        const double* G = bp.G[v];
+        d[0] -= (G[0] * S2 * vs.sig[v][0][1] + G[1] * S2 * vs.sig[v][1][0]) * inv_n;
+        d[1] -= (G[2] * S1 * vs.sig[v][0][1] + G[3] * S2 * vs.sig[v][1][1]) * inv_n;
+        d[2] -= (G[0] * A1 * vs.alp[v][0][0] + G[1] * A2 * vs.alp[v][1][0]) * inv_n;
+        d[3] -= (G[2] * A1 * vs.alp[v][0][1] + G[3] * A2 * vs.alp[v][1][1]) * inv_n;
+    }
 }
 
 #define CORR_NT 1024      // one workgroup
 #define CORR_PER_MAX 4    // blocks per thread: T <= 1024 * 4
 
 __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
-                                                  int pstride, int T, IrSums irs, double inv_n, int compat,
+                                                  int pstride, int T, VoiceSums vs, double inv_n, int compat,
                                                   double* __restrict__ cring, int rc, int64_t tabs0) {
     // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc).
-    // Thread tid owns the `per` consecutive blocks tid*per ..; their loads are issued together, running
-    // sums stay in registers, one 1024-wide scan joins the threads.  (Small code on purpose: a
-    // single-workgroup kernel this short is bound by instruction fetch, not by arithmetic.)
     __shared__ double s_part[CORR_NT][4];
     const int tid = threadIdx.x;
     const int per = (T + CORR_NT - 1) / CORR_NT;
@@ -485,8 +572,8 @@ __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sum
         const int tc = min(t, T - 1);  // clamped, unconditional loads; masked by select
         const float4 v = sums[tc];
         const BlockParams* bp = ptab + (int64_t)tc * pstride;
-        double d[4] = {0, 0, 0, 0};
-        corr_terms(v, *bp, irs, inv_n, d);
+        double d[4];
+        corr_terms(v, *bp, vs, inv_n, d);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             run[c] += ok ? d[c] : 0.0;
@@ -527,18 +614,20 @@ __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sum
 // taps + 255 + predelay > N_ref that cuts real signal: every output sample tau
 // loses  sum_{t: 256 t <= tau - N_ref} w_t[tau - predelay - 256 t].  The lost
 // terms are recomputed here in the time domain (a 256-term dot product per
-// affected block and path) and subtracted before the clamp; the host enables
-// the pass only in that regime.  Needs the input history (ring), the gains of
-// past blocks (ring) and the time-domain IRs.
+// affected block, voice and path) and subtracted before the clamp; the host
+// enables the pass only in that regime.  Needs the input history (ring), the
+// gains of past blocks (ring) and the time-domain IRs.
 // ---------------------------------------------------------------------------
 struct TailDrop {
     int on;
-    const float2* h0;  // time-domain taps {L, R} of the IR selected by half 0 (input 1)
-    const float2* h1;  // ... half 1 (input 2)
-    int L0, L1;        // taps
-    float* xhist;      // [2][xr] input history ring (absolute sample index mod xr)
+    int nv;                     // voices to consider
+    const float2* h0[MC_MAXV];  // time-domain taps {L, R} of voice v's IR for input 1
+    const float2* h1[MC_MAXV];  // ... for input 2
+    int L0[MC_MAXV], L1[MC_MAXV];
+    int lmax;
+    float* xhist;   // [2][xr] input history ring (absolute sample index mod xr)
     int xr;
-    float4* gring;     // [rc] wet gains {L<-in1, L<-in2, R<-in1, R<-in2} of past blocks
+    float4* gring;  // [MC_MAXV][rc] wet gains of past blocks
 };
 
 __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
@@ -548,53 +637,64 @@ __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64
     dl = dr = 0.f;
     const int64_t v = tau - n_ref;
     if (v < 0) return;
-    const int lmax = max(td.L0, td.L1);
     const int64_t hi_tb = v >> 8;
-    int64_t lo = tau - pd - 254 - lmax;
-    int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
+    const int64_t lo = tau - pd - 254 - td.lmax;
+    const int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
     for (int64_t tb = lo_tb; tb <= hi_tb; tb++) {
         const int64_t s = tau - pd - (tb << 8);  // position inside block tb's contribution, >= n_ref - pd
-        float4 g;
         const int64_t rel = tb - (tau0 >> 8);
-        if (rel >= 0 && rel < T) {
-            const BlockParams& bp = ptab[rel * pstride];
-            g = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
-        } else {
-            g = td.gring[(size_t)(tb & (rc - 1))];
-        }
-        float aL0 = 0.f, aR0 = 0.f, aL1 = 0.f, aR1 = 0.f;
         const int64_t base = tb << 8;
-        for (int m = 0; m < MC_B; m++) {
-            const int64_t j = s - m;
-            if (j < 0) break;
-            const int64_t sig = base + m;
-            float x1, x2;
-            if (sig >= tau0) {
-                x1 = cur1[sig - tau0];
-                x2 = cur2[sig - tau0];
+        for (int vi = 0; vi < td.nv; vi++) {
+            float4 g;
+            if (rel >= 0 && rel < T) {
+                const float* gv = ptab[rel * pstride].g[vi];
+                g = make_float4(gv[0], gv[1], gv[2], gv[3]);
             } else {
-                x1 = td.xhist[(size_t)(sig & (td.xr - 1))];
-                x2 = td.xhist[(size_t)td.xr + (sig & (td.xr - 1))];
+                g = td.gring[(size_t)vi * rc + (size_t)(tb & (rc - 1))];
             }
-            if (j < td.L0) {
-                const float2 h = td.h0[j];
-                aL0 = fmaf(x1, h.x, aL0);
-                aR0 = fmaf(x1, h.y, aR0);
+            if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+            float aL0 = 0.f, aR0 = 0.f, aL1 = 0.f, aR1 = 0.f;
+            for (int m = 0; m < MC_B; m++) {
+                const int64_t j = s - m;
+                if (j < 0) break;
+                const int64_t sig = base + m;
+                float x1, x2;
+                if (sig >= tau0) {
+                    x1 = cur1[sig - tau0];
+                    x2 = cur2[sig - tau0];
+                } else {
+                    x1 = td.xhist[(size_t)(sig & (td.xr - 1))];
+                    x2 = td.xhist[(size_t)td.xr + (sig & (td.xr - 1))];
+                }
+                if (j < td.L0[vi]) {
+                    const float2 h = td.h0[vi][j];
+                    aL0 = fmaf(x1, h.x, aL0);
+                    aR0 = fmaf(x1, h.y, aR0);
+                }
+                if (j < td.L1[vi]) {
+                    const float2 h = td.h1[vi][j];
+                    aL1 = fmaf(x2, h.x, aL1);
+                    aR1 = fmaf(x2, h.y, aR1);
+                }
             }
-            if (j < td.L1) {
-                const float2 h = td.h1[j];
-                aL1 = fmaf(x2, h.x, aL1);
-                aR1 = fmaf(x2, h.y, aR1);
-            }
+            dl += g.x * aL0 + g.y * aL1;
+            dr += g.z * aR0 + g.w * aR1;
         }
-        dl += g.x * aL0 + g.y * aL1;
-        dr += g.z * aR0 + g.w * aR1;
     }
 }
 
+// history for later calls: input samples and this block's wet gains (Q8 pass)
+__device__ __forceinline__ void write_history(const TailDrop& td, int64_t tau, int64_t tblock, int m, float x1, float x2,
+                                              const BlockParams& bp, int rc) {
+    td.xhist[(size_t)(tau & (td.xr - 1))] = x1;
+    td.xhist[(size_t)td.xr + (tau & (td.xr - 1))] = x2;
+    if (m < MC_MAXV)
+        td.gring[(size_t)m * rc + (size_t)(tblock & (rc - 1))] = make_float4(bp.g[m][0], bp.g[m][1], bp.g[m][2], bp.g[m][3]);
+}
+
 // ---------------------------------------------------------------------------
-// K6: predelay + Q1/Q2 window sums + saturating clamp + dry mix
-// (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
+// K6: overlap-add + predelay + Q1/Q2 window sums + Q8 + saturating clamp + dry
+// mix (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
 // conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, int seg0, const float* __restrict__ lin,
@@ -643,10 +743,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     }
     const BlockParams& bp = ptab[(int64_t)t * pstride];
     const float x1 = in1[i], x2 = in2[i];
-    // history for later calls: input samples and this block's wet gains (Q8 pass)
-    td.xhist[(size_t)(tau & (td.xr - 1))] = x1;
-    td.xhist[(size_t)td.xr + (tau & (td.xr - 1))] = x2;
-    if (m == 0) td.gring[(size_t)((tabs0 + t) & (rc - 1))] = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
+    write_history(td, tau, tabs0 + t, m, x1, x2, bp, rc);
     if (td.on) {
         float dl, dr;
         tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr);
@@ -665,26 +762,31 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
 // needs the new block, in one workgroup:
 //   wave 0: forward transform of the block (read straight from mapped host
 //           memory), delay-line slot, S/A sums          | waves 1-3: add the chunk partials
-//   all   : p = 0 term  H_{.,.,0} (x) X[t]  for the 256 bins
+//   all   : p = 0 term  g_v H_{v,.,0} (x) X[t]  for the 256 bins and every voice
 //   wave 0: packed inverse transform
 //   all   : overlap-add with the previous tail, Q1/Q2 prefix update, predelay,
-//           clamp, dry mix, output straight to mapped host memory.
+//           Q8, clamp, dry mix, output straight to mapped host memory.
 // Replaces, for nframes = 256, the whole body of onProcess (conv.cu:321-451).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, const float* __restrict__ in2,
-                                               const float4* __restrict__ H0, const float4* __restrict__ H1,
-                                               int pstride_ir, int do_p0, float4* __restrict__ fdl,
-                                               float4* __restrict__ slotpan, int ring, int slot0,
-                                               const float4* __restrict__ part, int nchunk, int have_part,
+struct VoiceSet {
+    int n;                      // voices with a partition-0 term
+    int vid[MC_MAXV];           // their gain-table rows
+    const float4* H0[MC_MAXV];  // spectra of the voice's IR for input 1 / input 2
+    const float4* H1[MC_MAXV];
+};
+
+__global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, const float* __restrict__ in2, VoiceSet vset,
+                                               int pstride_ir, float4* __restrict__ fdl, float4* __restrict__ slotgain,
+                                               int ring, int slot0, const float4* __restrict__ part, int nsum,
                                                const BlockParams* __restrict__ ptab, float* __restrict__ seg, int sr,
                                                int seg0, float* __restrict__ wet, int wr, double* __restrict__ cring,
-                                               int rc, IrSums irs, double inv_n, int compat, int64_t tabs0,
+                                               int rc, VoiceSums vs, double inv_n, int compat, int64_t tabs0,
                                                int64_t predelay, int64_t n_ref, float* __restrict__ outL,
                                                float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
-    __shared__ float4 s_x[MC_NB];   // scaled spectra of the new block {X1, X2}
-    __shared__ float4 s_y[MC_NB];   // Y_L, Y_R
+    __shared__ float4 s_x[MC_NB];  // raw spectra of the new block {X1, X2}
+    __shared__ float4 s_y[MC_NB];  // Y_L, Y_R
     __shared__ float s_wet[2][MC_B];
     __shared__ float s_in[2][MC_B];
     __shared__ double s_c[4];
@@ -716,49 +818,51 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                 x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
                 x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
             }
-            const float4 xs = make_float4(x1.x * bp.s[0], x1.y * bp.s[0], x2.x * bp.s[1], x2.y * bp.s[1]);
+            const float4 xs = make_float4(x1.x, x1.y, x2.x, x2.y);
             s_x[k] = xs;
             fdl[(size_t)k * ring + slot0] = xs;
         }
-        if (lane == 0) slotpan[slot0] = make_float4(bp.pan[0], bp.pan[1], bp.pan[2], bp.pan[3]);
+        if (lane < MC_MAXV)
+            slotgain[(size_t)lane * ring + slot0] = make_float4(bp.g[lane][0], bp.g[lane][1], bp.g[lane][2], bp.g[lane][3]);
     } else {
         for (int k = tid - 64; k < MC_NB; k += 192) {
             float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (have_part) {
-                const float4* src = part + (size_t)k * nchunk;
-                for (int c = 0; c < nchunk; c++) {
-                    const float4 a = src[c];
-                    y.x += a.x;
-                    y.y += a.y;
-                    y.z += a.z;
-                    y.w += a.w;
-                }
+            const float4* src = part + (size_t)k * nsum;
+            for (int c = 0; c < nsum; c++) {
+                const float4 a = src[c];
+                y.x += a.x;
+                y.y += a.y;
+                y.z += a.z;
+                y.w += a.w;
             }
             s_y[k] = y;
         }
     }
     __syncthreads();
-    if (do_p0) {  // partition 0 of both IRs against the new block
+    if (vset.n > 0) {  // partition 0 of every voice's IRs against the new block
         const int k = tid;
         const float4 x = s_x[k];
-        const float4 h0 = H0[(size_t)k * pstride_ir], h1 = H1[(size_t)k * pstride_ir];
-        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        if (k == 0) {
-            cmac<true>(a0, h0.x, h0.y, x.x, x.y);
-            cmac<true>(a1, h1.x, h1.y, x.z, x.w);
-            cmac<true>(a2, h0.z, h0.w, x.x, x.y);
-            cmac<true>(a3, h1.z, h1.w, x.z, x.w);
-        } else {
-            cmac<false>(a0, h0.x, h0.y, x.x, x.y);
-            cmac<false>(a1, h1.x, h1.y, x.z, x.w);
-            cmac<false>(a2, h0.z, h0.w, x.x, x.y);
-            cmac<false>(a3, h1.z, h1.w, x.z, x.w);
-        }
         float4 y = s_y[k];
-        y.x += bp.pan[0] * a0.x + bp.pan[1] * a1.x;
-        y.y += bp.pan[0] * a0.y + bp.pan[1] * a1.y;
-        y.z += bp.pan[2] * a2.x + bp.pan[3] * a3.x;
-        y.w += bp.pan[2] * a2.y + bp.pan[3] * a3.y;
+        for (int vi = 0; vi < vset.n; vi++) {
+            const float* g = bp.g[vset.vid[vi]];
+            const float4 h0 = vset.H0[vi][(size_t)k * pstride_ir], h1 = vset.H1[vi][(size_t)k * pstride_ir];
+            float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            if (k == 0) {
+                cmac<true>(a0, h0.x, h0.y, x.x, x.y);
+                cmac<true>(a1, h1.x, h1.y, x.z, x.w);
+                cmac<true>(a2, h0.z, h0.w, x.x, x.y);
+                cmac<true>(a3, h1.z, h1.w, x.z, x.w);
+            } else {
+                cmac<false>(a0, h0.x, h0.y, x.x, x.y);
+                cmac<false>(a1, h1.x, h1.y, x.z, x.w);
+                cmac<false>(a2, h0.z, h0.w, x.x, x.y);
+                cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+            }
+            y.x += g[0] * a0.x + g[1] * a1.x;
+            y.y += g[0] * a0.y + g[1] * a1.y;
+            y.z += g[2] * a2.x + g[3] * a3.x;
+            y.w += g[2] * a2.y + g[3] * a3.y;
+        }
         s_y[k] = y;
     }
     __syncthreads();
@@ -805,7 +909,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         s_wet[1][m] = wr_;
         if (m == 0) {
             double d[4] = {0, 0, 0, 0};
-            if (compat) corr_terms(s_sa, bp, irs, inv_n, d);
+            if (compat) corr_terms(s_sa, bp, vs, inv_n, d);
             const double* pb = cring + (size_t)((tabs0 + rc - 1) & (rc - 1)) * 4;
             double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
             for (int c = 0; c < 4; c++) {
@@ -851,9 +955,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             cr = a[1] + sg * a[3];
         }
         const float x1 = s_in[0][m], x2 = s_in[1][m];
-        td.xhist[(size_t)(tau & (td.xr - 1))] = x1;
-        td.xhist[(size_t)td.xr + (tau & (td.xr - 1))] = x2;
-        if (m == 0) td.gring[(size_t)(tabs0 & (rc - 1))] = make_float4((float)bp.G[0], (float)bp.G[1], (float)bp.G[2], (float)bp.G[3]);
+        write_history(td, tau, tabs0, m, x1, x2, bp, rc);
         if (td.on) {
             float dl, dr;
             tail_drop(td, tau, tabs0 * MC_B, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr);

@@ -77,11 +77,11 @@ struct mc_engine {
     IrEntry irs[kMaxIrs];
     int nirs = 0;
 
-    float4 *d_fdl = nullptr, *d_slotpan = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
-    float *d_seg = nullptr, *d_wet = nullptr, *d_lin = nullptr;
+    float4 *d_fdl = nullptr, *d_slotgain = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
+    float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
     float* d_xhist = nullptr;   // [2][xr] input history (Q8 pass)
-    float4* d_gring = nullptr;  // [rc] wet gains of past blocks (Q8 pass)
+    float4* d_gring = nullptr;  // [MC_MAXV][rc] wet gains of past blocks (Q8 pass)
     int xr = 0;
     BlockParams* d_ptab = nullptr;
     float2* d_tw = nullptr;
@@ -97,8 +97,22 @@ struct mc_engine {
     std::mutex pmu;
     mc_cc_value cc[2];
 
-    // signal state
-    double e[2] = {0, 0};  // cross-fade coefficient of each half's selected IR (Q7)
+    // Cross-fade state.  The reference keeps live spectra irFFT_i and pulls them towards
+    // wet_i * H_sel_i every block: irFFT += (wet H_sel - irFFT)/(vsteps+5) (conv.cu:27, 339-353).
+    // irFFT_i is therefore always sum_j c_ij H_j with c_ij <- c_ij (1 - 1/(v+5)) + [j == sel_i] wet_i/(v+5):
+    // one coefficient per IR that has been selected recently.  coef[i][v] is that coefficient for
+    // the IR in voice slot v of half i.
+    struct VoiceSlot {
+        int ir = -1;           // IR index, -1 = free
+        double coef = 0.0;
+        uint64_t last_nz = 0;  // last block whose gain for this slot was non-zero
+        bool ever = false;
+    } voice[2][MC_MAXV];
+    float last_g[MC_MAXV][4];
+    uint64_t gain_change_block[MC_MAXV] = {0, 0, 0};  // block at which voice v's gains last changed
+    uint64_t last_nz_voice[MC_MAXV] = {0, 0, 0};
+    bool voice_ever[MC_MAXV] = {false, false, false};
+
     uint64_t t_abs = 0;    // blocks finished (front + back done)
     uint64_t t_front = 0;  // blocks whose front half (FFT, MAC, inverse, overlap-add) has been issued
     // up to kPipe batches may sit between their front and back halves (sharded
@@ -108,18 +122,18 @@ struct mc_engine {
         uint64_t t0 = 0;
         int pstride = 1;
         uint64_t predelay = 0;
-        IrSums irs;
+        VoiceSums vs;
+        int vir[2][MC_MAXV];  // IR index per half and voice (-1 = none)
         int slot = 0;
-        uint64_t sel[2] = {0, 0};
     } pipe[2];
     int pipe_head = 0, pipe_count = 0;
     uint64_t batch_seq = 0;
     // speculative MAC of the next single block (partitions >= 1 do not depend on the next input)
     bool speculate = true, spec_valid = false;
-    uint64_t spec_block = 0, spec_sel[2] = {0, 0};
+    uint64_t spec_block = 0;
+    int spec_vir[2][MC_MAXV];
+    int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
-    float last_pan[4] = {-2.f, -2.f, -2.f, -2.f};
-    uint64_t pan_change_block = 0;  // first block that carried the current wet pans
     bool uniform_valid[2] = {false, false};
     BlockParams uniform_bp[2];
 
@@ -165,51 +179,103 @@ int drain_kernel_events(mc_engine* e) {
 int zero_state(mc_engine* e) {
     if (e->side) HIP_TRY(hipStreamSynchronize(e->side));
     HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_slotpan, 0, sizeof(float4) * (size_t)e->ring, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_slotgain, 0, sizeof(float4) * (size_t)MC_MAXV * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_wet, 0, sizeof(float) * 2 * (size_t)e->wr, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_cring, 0, sizeof(double) * 4 * (size_t)e->rc, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_xhist, 0, sizeof(float) * 2 * (size_t)e->xr, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_gring, 0, sizeof(float4) * (size_t)e->rc, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_gring, 0, sizeof(float4) * (size_t)MC_MAXV * e->rc, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->e[0] = e->e[1] = 0.0;
+    for (int i = 0; i < 2; i++)
+        for (int v = 0; v < MC_MAXV; v++) e->voice[i][v] = mc_engine::VoiceSlot();
+    for (int v = 0; v < MC_MAXV; v++) {
+        for (int c = 0; c < 4; c++) e->last_g[v][c] = 0.f;
+        e->gain_change_block[v] = 0;
+        e->last_nz_voice[v] = 0;
+        e->voice_ever[v] = false;
+    }
     e->t_abs = e->t_front = 0;
-    e->last_pan[0] = -2.f;
-    e->pan_change_block = 0;
     e->spec_valid = false;
     e->uniform_valid[0] = e->uniform_valid[1] = false;
     e->pipe_head = e->pipe_count = 0;
     return MC_OK;
 }
 
-// Build the per-block parameter table for T blocks starting now (host, double).
-// Advances the cross-fade coefficients exactly like f_interpolate + vsteps--
-// (conv.cu:27, 339-353).  Returns pstride (0 = one entry serves all blocks).
+// voice slot of half i that holds IR `ir`; allocates a free (fully retired) slot when it is new
+int voice_slot_for(mc_engine* e, int i, int ir, uint64_t block) {
+    mc_engine::VoiceSlot* vs = e->voice[i];
+    for (int v = 0; v < MC_MAXV; v++)
+        if (vs[v].ir == ir) return v;
+    // a slot may be reused once its last non-zero gain has left every window (longest IR = Pcap blocks)
+    for (int v = 0; v < MC_MAXV; v++)
+        if (vs[v].ir < 0 || (vs[v].coef == 0.0 && (!vs[v].ever || vs[v].last_nz + (uint64_t)e->Pcap + 1 < block))) {
+            vs[v] = mc_engine::VoiceSlot();
+            vs[v].ir = ir;
+            return v;
+        }
+    // more than MC_MAXV IRs cross-fading within one IR length: drop the quietest (documented limit)
+    int q = 0;
+    for (int v = 1; v < MC_MAXV; v++)
+        if (std::fabs(vs[v].coef) < std::fabs(vs[q].coef)) q = v;
+    vs[q] = mc_engine::VoiceSlot();
+    vs[q].ir = ir;
+    return q;
+}
+
+// Build the per-block parameter table for T blocks starting at block e->t_front (host, double).
+// Advances the cross-fade coefficients exactly like f_interpolate + vsteps-- (conv.cu:27, 339-353).
+// Returns pstride (0 = one entry serves all blocks).
 int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_tab, int* out_n) {
     BlockParams* tab = e->h_ptab[e->ptab_next];
     bool all_same = true;
     for (int t = 0; t < T; t++) {
+        const uint64_t blk = e->t_front + (uint64_t)t;
         BlockParams& bp = tab[t];
+        std::memset(&bp, 0, sizeof(bp));
         for (int i = 0; i < 2; i++) {
-            double wet = (double)cc[i].wet;
-            e->e[i] += (wet - e->e[i]) / (double)(cc[i].vsteps + 5);
-            if (std::fabs(wet - e->e[i]) <= 1e-300 + 4e-16 * std::fabs(wet)) e->e[i] = wet;
+            const double wet = (double)cc[i].wet;
+            const double div = (double)(cc[i].vsteps + 5);
+            const int sv = voice_slot_for(e, i, (int)cc[i].select, blk);
+            for (int v = 0; v < MC_MAXV; v++) {
+                mc_engine::VoiceSlot& s = e->voice[i][v];
+                if (s.ir < 0) continue;
+                const double target = (v == sv) ? wet : 0.0;
+                s.coef += (target - s.coef) / div;
+                // settle: the recurrence converges geometrically; snap once the distance is below double
+                // resolution of the reference's float spectra (keeps steady-state tables bit-identical)
+                if (std::fabs(target - s.coef) <= 1e-300 + 4e-16 * std::fabs(target) || (target == 0.0 && std::fabs(s.coef) < 1e-30))
+                    s.coef = target;
+            }
             if (cc[i].vsteps > 0) cc[i].vsteps--;
         }
         for (int i = 0; i < 2; i++) {
             const double lvl = (double)cc[i].level;
             const double pl = pan_l((double)cc[i].panWet), pr = pan_r((double)cc[i].panWet);
-            bp.s[i] = (float)(lvl * e->e[i]);
-            // G uses the float-rounded delay-line scale so that the Q1/Q2 terms
-            // match what the MAC actually accumulates
-            bp.G[0 * 2 + i] = pl * lvl * e->e[i];
-            bp.G[1 * 2 + i] = pr * lvl * e->e[i];
-            bp.pan[0 * 2 + i] = (float)pl;
-            bp.pan[1 * 2 + i] = (float)pr;
+            for (int v = 0; v < MC_MAXV; v++) {
+                mc_engine::VoiceSlot& s = e->voice[i][v];
+                const double c = s.ir >= 0 ? s.coef : 0.0;
+                bp.G[v][0 * 2 + i] = pl * lvl * c;
+                bp.G[v][1 * 2 + i] = pr * lvl * c;
+                bp.g[v][0 * 2 + i] = (float)bp.G[v][0 * 2 + i];
+                bp.g[v][1 * 2 + i] = (float)bp.G[v][1 * 2 + i];
+                if (bp.g[v][0 * 2 + i] != 0.f || bp.g[v][1 * 2 + i] != 0.f) {
+                    s.last_nz = blk;
+                    s.ever = true;
+                }
+            }
             bp.d[0 * 2 + i] = (float)((double)cc[i].dry * pan_l((double)cc[i].panDry) * lvl);
             bp.d[1 * 2 + i] = (float)((double)cc[i].dry * pan_r((double)cc[i].panDry) * lvl);
         }
-        bp.pad0[0] = bp.pad0[1] = 0.f;
+        for (int v = 0; v < MC_MAXV; v++) {
+            if (std::memcmp(e->last_g[v], bp.g[v], sizeof(bp.g[v])) != 0) {
+                std::memcpy(e->last_g[v], bp.g[v], sizeof(bp.g[v]));
+                e->gain_change_block[v] = blk;
+            }
+            if (bp.g[v][0] != 0.f || bp.g[v][1] != 0.f || bp.g[v][2] != 0.f || bp.g[v][3] != 0.f) {
+                e->last_nz_voice[v] = blk;
+                e->voice_ever[v] = true;
+            }
+        }
         if (t > 0 && std::memcmp(&tab[t], &tab[0], sizeof(BlockParams)) != 0) all_same = false;
     }
     *out_tab = tab;
@@ -217,10 +283,13 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
     return all_same ? 0 : 1;
 }
 
-struct BatchCtx {
-    int T;
-    int slot0, seg0;
-    int64_t tau0;
+// One voice as the MAC sees it
+struct ActiveVoice {
+    int v;                 // gain-table row
+    const IrEntry *ir0, *ir1;
+    int p_end;             // partitions to sweep (multiple of 16), before sharding
+    bool uniform;          // every slot of the window carries the same gains
+    float4 ugain;
 };
 
 // Sample the parameters, advance the cross-fade, stage the per-block table of a
@@ -229,9 +298,16 @@ struct Staged {
     mc_engine::BatchCtx ctx;
     BlockParams* d_ptab;
     float4* d_sums;
-    const IrEntry *ir0, *ir1;
     BlockParams first;  // host copy of the first block's parameters
+    ActiveVoice act[MC_MAXV];
+    int nact = 0;
 };
+
+const IrEntry* any_ir(const mc_engine* e) {
+    for (int i = 0; i < kMaxIrs; i++)
+        if (e->irs[i].d_H) return &e->irs[i];
+    return nullptr;
+}
 
 int stage_params(mc_engine* e, int T, Staged* st) {
     const int bslot = (int)(e->batch_seq % kPipe);
@@ -247,8 +323,6 @@ int stage_params(mc_engine* e, int T, Staged* st) {
             return fail(MC_ERR_STATE, "half %d selects IR %llu which is not loaded", i, (unsigned long long)cc[i].select);
     }
     if (cc[0].predelay > MC_MAX_PREDELAY) return fail(MC_ERR_ARG, "predelay %llu > %d", (unsigned long long)cc[0].predelay, MC_MAX_PREDELAY);
-    const IrEntry& ir0 = e->irs[cc[0].select];
-    const IrEntry& ir1 = e->irs[cc[1].select];
 
     BlockParams* tab;
     int ntab;
@@ -274,73 +348,90 @@ int stage_params(mc_engine* e, int T, Staged* st) {
         e->uniform_valid[bslot] = (pstride == 0);
         if (pstride == 0) e->uniform_bp[bslot] = tab[0];
     }
-    // when did the wet pans last change?  (the streaming kernel may use one pan for every slot
-    // once the change is older than the longest IR)
-    for (int t = 0; t < ntab; t++) {
-        if (std::memcmp(e->last_pan, tab[t].pan, sizeof(e->last_pan)) != 0) {
-            std::memcpy(e->last_pan, tab[t].pan, sizeof(e->last_pan));
-            e->pan_change_block = e->t_front + (uint64_t)t;
-        }
-    }
     st->first = tab[0];
     st->d_ptab = d_ptab;
     st->d_sums = e->d_sums + (size_t)bslot * e->Tmax;
-    st->ir0 = &ir0;
-    st->ir1 = &ir1;
     st->ctx.T = T;
     st->ctx.t0 = e->t_front;
     st->ctx.pstride = pstride;
     st->ctx.predelay = cc[0].predelay;
     st->ctx.slot = bslot;
-    st->ctx.sel[0] = cc[0].select;
-    st->ctx.sel[1] = cc[1].select;
-    for (int c = 0; c < 2; c++) {
-        st->ctx.irs.sig[0][c] = ir0.sums[c];
-        st->ctx.irs.sig[1][c] = ir1.sums[c];
-        st->ctx.irs.alp[0][c] = ir0.sums[2 + c];
-        st->ctx.irs.alp[1][c] = ir1.sums[2 + c];
+    std::memset(&st->ctx.vs, 0, sizeof(st->ctx.vs));
+    const IrEntry* fallback = any_ir(e);
+    st->nact = 0;
+    for (int v = 0; v < MC_MAXV; v++) {
+        const IrEntry* ir[2];
+        for (int i = 0; i < 2; i++) {
+            const int idx = e->voice[i][v].ir;
+            st->ctx.vir[i][v] = (idx >= 0 && e->irs[idx].d_H) ? idx : -1;
+            ir[i] = st->ctx.vir[i][v] >= 0 ? &e->irs[idx] : nullptr;
+            if (ir[i]) {
+                for (int c = 0; c < 2; c++) {
+                    st->ctx.vs.sig[v][i][c] = ir[i]->sums[c];
+                    st->ctx.vs.alp[v][i][c] = ir[i]->sums[2 + c];
+                }
+            }
+        }
+        if (!ir[0] && !ir[1]) continue;
+        ActiveVoice a;
+        a.v = v;
+        a.ir0 = ir[0] ? ir[0] : (ir[1] ? ir[1] : fallback);  // a missing half has zero gains; any valid spectra do
+        a.ir1 = ir[1] ? ir[1] : a.ir0;
+        a.p_end = round_up(std::max(ir[0] ? ir[0]->P : 0, ir[1] ? ir[1]->P : 0), 16);
+        // sounding in this batch's windows?  (last non-zero gain not older than the sweep)
+        if (!e->voice_ever[v] || e->last_nz_voice[v] + (uint64_t)a.p_end < e->t_front) continue;
+        a.uniform = e->gain_change_block[v] + (uint64_t)a.p_end <= e->t_front;
+        a.ugain = make_float4(tab[0].g[v][0], tab[0].g[v][1], tab[0].g[v][2], tab[0].g[v][3]);
+        st->act[st->nact++] = a;
     }
     return MC_OK;
 }
 
 // Q8 pass descriptor: enabled only when some contribution is shifted past n_ref by the predelay
-TailDrop make_taildrop(const mc_engine* e, const IrEntry& ir0, const IrEntry& ir1, uint64_t predelay) {
+TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_t predelay) {
     TailDrop td;
-    const uint64_t lmax = std::max(ir0.taps, ir1.taps);
+    std::memset(&td, 0, sizeof(td));
+    const IrEntry* fb = any_ir(e);
+    uint64_t lmax = 0;
+    td.nv = MC_MAXV;
+    for (int v = 0; v < MC_MAXV; v++) {
+        const IrEntry* a = vir[0][v] >= 0 ? &e->irs[vir[0][v]] : nullptr;
+        const IrEntry* b = vir[1][v] >= 0 ? &e->irs[vir[1][v]] : nullptr;
+        td.h0[v] = a ? a->d_h : (fb ? fb->d_h : nullptr);
+        td.h1[v] = b ? b->d_h : (fb ? fb->d_h : nullptr);
+        td.L0[v] = a ? (int)a->taps : 0;
+        td.L1[v] = b ? (int)b->taps : 0;
+        lmax = std::max<uint64_t>(lmax, std::max<uint64_t>(td.L0[v], td.L1[v]));
+    }
+    td.lmax = (int)lmax;
     td.on = (e->cfg.compat && lmax + 255 + predelay > e->cfg.n_ref) ? 1 : 0;
-    td.h0 = ir0.d_h;
-    td.h1 = ir1.d_h;
-    td.L0 = (int)ir0.taps;
-    td.L1 = (int)ir1.taps;
     td.xhist = e->d_xhist;
     td.xr = e->xr;
     td.gring = e->d_gring;
     return td;
 }
 
-// partition range [p_begin, p_end) this engine sweeps for the two selected IRs (multiples of 16)
-void partition_range(const mc_engine* e, const IrEntry& ir0, const IrEntry& ir1, int* p_begin, int* p_end) {
-    const int p_hi = round_up(std::max(ir0.P, ir1.P), 16);
+// shard of a voice's partition range [p_begin, p_end), multiples of 16
+void partition_range(const mc_engine* e, int p_hi, int* p_begin, int* p_end) {
     int pb = (int)e->cfg.part_begin, pe = e->cfg.part_end ? std::min<int>((int)e->cfg.part_end, p_hi) : p_hi;
     if (pb > pe) pb = pe;
     *p_begin = pb;
     *p_end = pe;
 }
 
-void launch_mac_stream(mc_engine* e, bool uniform, const IrEntry& ir0, const IrEntry& ir1, int p_lo, int p_hi, int T, int slot0,
-                       float4 upan) {
+void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, int T, int slot0, int nsum, int ch_off) {
     const int nt = e->stream_nt;
     const int span = p_hi - p_lo;
-    // one loop trip per lane covers nt * STREAM_U partitions; chunks are multiples of 64
     const int chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
     const dim3 grid(MC_NB, e->nchunk, T);
-#define MC_LAUNCH_STREAM(U, NT)                                                                                          \
-    hipLaunchKernelGGL((k_mac_stream<U, NT>), grid, dim3(NT), 0, e->stream, ir0.d_H, ir1.d_H, e->Pstride, p_lo, p_hi, chunk, \
-                       e->d_fdl, e->d_slotpan, e->ring, slot0, e->d_part, e->nchunk, upan)
+    const float4* sg = e->d_slotgain + (size_t)a.v * e->ring;
+#define MC_LAUNCH_STREAM(U, NT)                                                                                             \
+    hipLaunchKernelGGL((k_mac_stream<U, NT>), grid, dim3(NT), 0, e->stream, a.ir0->d_H, a.ir1->d_H, e->Pstride, p_lo, p_hi, \
+                       chunk, e->d_fdl, sg, e->ring, slot0, e->d_part, nsum, ch_off, a.ugain)
     if (nt == 512) {
-        if (uniform) MC_LAUNCH_STREAM(true, 512); else MC_LAUNCH_STREAM(false, 512);
+        if (a.uniform) MC_LAUNCH_STREAM(true, 512); else MC_LAUNCH_STREAM(false, 512);
     } else {
-        if (uniform) MC_LAUNCH_STREAM(true, 256); else MC_LAUNCH_STREAM(false, 256);
+        if (a.uniform) MC_LAUNCH_STREAM(true, 256); else MC_LAUNCH_STREAM(false, 256);
     }
 #undef MC_LAUNCH_STREAM
 }
@@ -358,29 +449,22 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     e->spec_valid = false;
     BlockParams* d_ptab = st.d_ptab;
     float4* d_sums = st.d_sums;
-    const IrEntry& ir0 = *st.ir0;
-    const IrEntry& ir1 = *st.ir1;
     const int pstride = st.ctx.pstride;
-    const BlockParams* tab = &st.first;
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
-    const int seg0 = (int)(e->t_front % (uint64_t)e->sr);
+    const int seg0 = (int)(e->t_front & (uint64_t)(e->sr - 1));
 
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
-                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotpan, e->d_tw);
+                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw);
     // Q1/Q2 prefix sums need only k_fwd's block sums: fork them to the side stream so they run beside the MAC
     HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
-    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->side, d_sums, d_ptab, pstride, T, st.ctx.irs,
+    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->side, d_sums, d_ptab, pstride, T, st.ctx.vs,
                        1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)st.ctx.t0);
     HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], e->side));
 
-    int p_begin, p_end;
-    partition_range(e, ir0, ir1, &p_begin, &p_end);
     const bool resident = T >= e->stream_threshold;
-    const bool empty = (p_end == p_begin);
-
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
     if (e->ktiming) {
         if (e->kev_n == kEvPool) {
@@ -393,42 +477,60 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         HIP_TRY(hipEventRecord(*k0, e->stream));
     }
     int64_t sk, stt;
-    int nsum;
+    int nsum, swept = 0, launched = 0;
     const float4* ysrc;
     if (resident) {
-        const float4 pan = make_float4(tab[0].pan[0], tab[0].pan[1], tab[0].pan[2], tab[0].pan[3]);
-        if (empty) {
-            HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * e->Tmax, e->stream));
-        } else {
-            hipLaunchKernelGGL(k_mac_resident, dim3(MC_NB * ((T + 255) / 256)), dim3(256), 0, e->stream, ir0.d_H, ir1.d_H,
-                               e->Pstride, p_begin, p_end, e->d_fdl, e->ring, slot0, T, pan, e->d_Y, e->Tmax);
+        for (int a = 0; a < st.nact; a++) {
+            const ActiveVoice& av = st.act[a];
+            int p_begin, p_end;
+            partition_range(e, av.p_end, &p_begin, &p_end);
+            if (p_end <= p_begin) continue;
+            const dim3 grid(MC_NB * ((T + 255) / 256));
+            const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
+            if (av.uniform && pstride == 0)
+                hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, e->Tmax, launched ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, e->Tmax, launched ? 1 : 0);
+            launched++;
+            swept = std::max(swept, p_end - p_begin);
         }
+        if (!launched) HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * e->Tmax, e->stream));
         ysrc = e->d_Y;
         sk = e->Tmax;
         stt = 1;
         nsum = 1;
     } else {
-        if (empty) {
-            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)T * MC_NB * e->nchunk, e->stream));
-        } else {
-            // one pan for all slots is exact when the last pan change is older than every slot the sweep touches
-            const bool upan_ok = st.ctx.pstride == 0 && e->t_front >= e->pan_change_block + (uint64_t)p_end;
-            const float4 upan = make_float4(tab[0].pan[0], tab[0].pan[1], tab[0].pan[2], tab[0].pan[3]);
-            launch_mac_stream(e, upan_ok, ir0, ir1, p_begin, p_end, T, slot0, upan);
+        // streaming: one set of chunk partials per sounding voice, all added by k_inv
+        int nv = 0;
+        ActiveVoice list[MC_MAXV];
+        int pb[MC_MAXV], pe[MC_MAXV];
+        for (int a = 0; a < st.nact; a++) {
+            partition_range(e, st.act[a].p_end, &pb[nv], &pe[nv]);
+            if (pe[nv] <= pb[nv]) continue;
+            list[nv] = st.act[a];
+            if (pstride != 0) list[nv].uniform = false;
+            nv++;
+        }
+        nsum = std::max(1, nv) * e->nchunk;
+        if (!nv) HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)T * MC_NB * nsum, e->stream));
+        for (int a = 0; a < nv; a++) {
+            launch_mac_stream(e, list[a], pb[a], pe[a], T, slot0, nsum, a * e->nchunk);
+            swept = std::max(swept, pe[a] - pb[a]);
         }
         ysrc = e->d_part;
-        sk = e->nchunk;
-        stt = (int64_t)MC_NB * e->nchunk;
-        nsum = e->nchunk;
+        sk = nsum;
+        stt = (int64_t)MC_NB * nsum;
     }
     if (e->ktiming) {
         HIP_TRY(hipEventRecord(*k1, e->stream));
         e->kev_n++;
         e->ks.resident = resident ? 1 : 0;
-        e->ks.partitions = (uint32_t)(p_end - p_begin);
+        e->ks.partitions = (uint32_t)swept;
     }
 
-    // K3, K4
+    // K3 (+ K4 for shards)
     hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, stt, nsum, T, e->d_seg,
                        e->sr, seg0, e->d_tw);
     if (lin) hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, lin);
@@ -453,10 +555,10 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_corr[ctx.slot], 0));
     if (d_outL && d_outR) {
         const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
-        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 % (uint64_t)e->sr), lin_sum,
-                           e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride,
-                           d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref,
-                           (int)e->cfg.compat, make_taildrop(e, e->irs[ctx.sel[0]], e->irs[ctx.sel[1]], ctx.predelay));
+        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
+                           e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
+                           (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
+                           make_taildrop(e, ctx.vir, ctx.predelay));
         HIP_TRY(hipGetLastError());
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
@@ -477,18 +579,34 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         int rc = stage_params(e, 1, &st);
         if (rc) return rc;
     }
-    const IrEntry& ir0 = *st.ir0;
-    const IrEntry& ir1 = *st.ir1;
-    int p_begin, p_end;
-    partition_range(e, ir0, ir1, &p_begin, &p_end);
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
-    const int seg0 = (int)(e->t_front % (uint64_t)e->sr);
-    const int do_p0 = (p_begin == 0 && p_end > 0) ? 1 : 0;
-    const int lo = std::max(p_begin, 1);
-    const int have_part = p_end > lo ? 1 : 0;
+    const int seg0 = (int)(e->t_front & (uint64_t)(e->sr - 1));
 
-    const uint64_t sel0 = (uint64_t)(st.ir0 - e->irs), sel1 = (uint64_t)(st.ir1 - e->irs);
-    // timed MAC launch (the kernel the roofline is quoted on); `blk` = the block it belongs to
+    // voices with partitions >= 1 to sweep, and voices with a partition-0 term
+    ActiveVoice sweep[MC_MAXV];
+    int lo[MC_MAXV], hi[MC_MAXV], nsweep = 0;
+    VoiceSet vset;
+    std::memset(&vset, 0, sizeof(vset));
+    for (int a = 0; a < st.nact; a++) {
+        int pb, pe;
+        partition_range(e, st.act[a].p_end, &pb, &pe);
+        if (pe <= pb) continue;
+        if (pb == 0) {
+            vset.vid[vset.n] = st.act[a].v;
+            vset.H0[vset.n] = st.act[a].ir0->d_H;
+            vset.H1[vset.n] = st.act[a].ir1->d_H;
+            vset.n++;
+        }
+        if (pe > std::max(pb, 1)) {
+            sweep[nsweep] = st.act[a];
+            lo[nsweep] = std::max(pb, 1);
+            hi[nsweep] = pe;
+            nsweep++;
+        }
+    }
+    const int nsum = std::max(1, nsweep) * e->nchunk;
+
+    // timed MAC launches (the kernel the roofline is quoted on); `blk` = the block they belong to
     auto launch_mac = [&](uint64_t blk) -> int {
         hipEvent_t *k0 = nullptr, *k1 = nullptr;
         if (e->ktiming) {
@@ -503,43 +621,59 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         }
         // partition p of block `blk` pairs with slot (blk - p); p >= 1 only touches blocks < blk
         const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
-        const bool upan_ok = blk >= e->pan_change_block + (uint64_t)p_end;
-        const float4 upan = make_float4(st.first.pan[0], st.first.pan[1], st.first.pan[2], st.first.pan[3]);
-        launch_mac_stream(e, upan_ok, ir0, ir1, lo, p_end, 1, bslot0, upan);
+        int swept = 0;
+        for (int a = 0; a < nsweep; a++) {
+            ActiveVoice av = sweep[a];
+            // one gain for all slots only when the last change is older than every slot of the sweep
+            av.uniform = e->gain_change_block[av.v] + (uint64_t)hi[a] <= blk && e->gain_change_block[av.v] < blk;
+            launch_mac_stream(e, av, lo[a], hi[a], 1, bslot0, nsum, a * e->nchunk);
+            swept = std::max(swept, hi[a] - (lo[a] == 1 ? 0 : lo[a]));
+        }
         if (e->ktiming) {
             HIP_TRY(hipEventRecord(*k1, e->stream));
             e->kev_n++;
             e->ks.resident = 0;
-            e->ks.partitions = (uint32_t)(p_end - p_begin);
+            e->ks.partitions = (uint32_t)swept;
         }
         return MC_OK;
     };
-    const bool spec_hit = e->spec_valid && e->spec_block == e->t_front && e->spec_sel[0] == sel0 && e->spec_sel[1] == sel1;
-    if (have_part && !spec_hit) {
-        int rc = launch_mac(e->t_front);
-        if (rc) return rc;
+    bool spec_hit = e->spec_valid && e->spec_block == e->t_front && e->spec_nact == nsweep;
+    if (spec_hit)
+        for (int a = 0; a < nsweep && spec_hit; a++)
+            spec_hit = e->spec_vir[0][a] == st.ctx.vir[0][sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][sweep[a].v];
+    if (!spec_hit) {
+        if (nsweep) {
+            int rc = launch_mac(e->t_front);
+            if (rc) return rc;
+        } else {
+            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)MC_NB * nsum, e->stream));
+        }
     }
     e->spec_valid = false;
-    hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, e->hd_io + 0 * cap, e->hd_io + 1 * cap, ir0.d_H, ir1.d_H,
-                       e->Pstride, do_p0, e->d_fdl, e->d_slotpan, e->ring, slot0, e->d_part, e->nchunk, have_part, st.d_ptab,
-                       e->d_seg, e->sr, seg0, e->d_wet, e->wr, e->d_cring, e->rc, st.ctx.irs, 1.0 / (double)e->cfg.n_ref,
-                       (int)e->cfg.compat, (int64_t)e->t_front, (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref,
-                       e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw, make_taildrop(e, ir0, ir1, st.ctx.predelay));
+    hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, e->hd_io + 0 * cap, e->hd_io + 1 * cap, vset, e->Pstride,
+                       e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, seg0, e->d_wet, e->wr,
+                       e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,
+                       (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
     e->t_front += 1;
     e->t_abs = e->t_front;
-    if (e->speculate && have_part) {
+    if (e->speculate && nsweep) {
         // In the shadow of the JACK period: the partition sweep of the NEXT block over partitions >= 1
-        // needs only blocks already in the delay line.  Per-slot pans are recorded with each block, so
-        // the result stays exact under any parameter change except an IR switch / reload (checked above).
+        // needs only blocks already in the delay line, and every slot carries its own gains, so the
+        // result stays exact under any parameter change except a change of the sounding IR set
+        // (checked above) or an IR reload.
         int rc = launch_mac(e->t_front);
         if (rc) return rc;
         e->spec_valid = true;
         e->spec_block = e->t_front;
-        e->spec_sel[0] = sel0;
-        e->spec_sel[1] = sel1;
+        e->spec_nact = nsweep;
+        for (int a = 0; a < nsweep; a++) {
+            e->spec_vir[0][a] = st.ctx.vir[0][sweep[a].v];
+            e->spec_vir[1][a] = st.ctx.vir[1][sweep[a].v];
+        }
     }
     HIP_TRY(hipEventSynchronize(e->ev_tail));  // the output of THIS block is on the host; the speculative sweep runs on
     std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
@@ -650,16 +784,16 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     e->stream = e->own_stream;
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
-    ENG_TRY(hipMalloc(&e->d_slotpan, sizeof(float4) * (size_t)e->ring));
+    ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
     ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * e->Tmax));
-    ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk));
+    ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
     e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B + MC_MAX_PREDELAY + 1024);
     ENG_TRY(hipMalloc(&e->d_xhist, sizeof(float) * 2 * (size_t)e->xr));
-    ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)e->rc));
+    ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
     ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
@@ -699,7 +833,7 @@ void mc_destroy(mc_engine* e) {
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     (void)hipFree(e->d_fdl);
-    (void)hipFree(e->d_slotpan);
+    (void)hipFree(e->d_slotgain);
     (void)hipFree(e->d_Y);
     (void)hipFree(e->d_part);
     (void)hipFree(e->d_sums);

@@ -486,3 +486,66 @@ def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack):
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
     c.close()
+
+
+@pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
+def test_live_ir_switch_crossfade(oracle_mod, gpu_lib, jack):
+    """select CCs while audio runs.  The reference pulls its live spectra towards the newly
+    selected IR over `speed` blocks (f_interpolate, conv.cu:15-32, 255-276, 339-353); the engine runs the
+    outgoing and incoming IRs as two voices whose coefficients follow the same recurrence.  Includes a
+    switch back before the first fade has finished, different speeds per half and a wet change mid-fade."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 140, 8192
+    x = make_input(nb * 256)
+    irs = [make_ir(5000, seed=11, norm=0.05), make_ir(4000, seed=22, norm=0.05), make_ir(6000, seed=33, norm=0.05)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=16)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    cmap = (21, 22, 23, 24, 25, 26, 27, 28)
+    # (block, half, controller, value): select = v * 3 / 128 -> IR index; speed = v * 1024 / 128
+    events = [(0, 0, 25, 2), (0, 1, 25, 1), (10, 0, 21, 64), (30, 1, 21, 100), (38, 0, 21, 0), (50, 0, 24, 90),
+              (70, 0, 21, 127), (70, 1, 21, 0)]
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+
+    class Dev:
+        pass
+
+    dev = Dev()
+    for half in (0, 1):
+        cc = c.cc[half]
+        cc.device, cc.message = dev, 176
+        cc.select, cc.predelay, cc.dry, cc.wet, cc.speed, cc.panDry, cc.panWet, cc.level = cmap
+    step = 1 if jack else 5
+    b = 0
+    while b < nb:
+        n = 1 if jack else min(step, nb - b)
+        if not jack:
+            # a batch may not straddle an event: cut it at the next one
+            nxt = min([ev[0] for ev in events if ev[0] > b] + [nb])
+            n = min(n, nxt - b)
+        for ev in events:
+            if ev[0] == b:
+                _, half, ctl, val = ev
+                oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
+                # one physical controller per half here: address the half directly through the C ABI
+                import ctypes as C
+
+                arr = (C.c_uint8 * 8)(*cmap)
+                assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
+        s = slice(b * 256, (b + n) * 256)
+        for k in range(n):
+            ss = slice((b + k) * 256, (b + k + 1) * 256)
+            want[:, ss] = ref.process(x[0, ss], x[1, ss])
+        if jack:
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        b += n
+    assert ref.cc(0).select == 2 and ref.cc(1).select == 0
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
