@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
                     help="resident: IR held on chip across the batch; stream: every block re-reads IR+delay line")
+    ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
+                    help="fp16: IR spectra and delay line stored as half for the streaming sweep (implies --mode stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-block-per-call (JACK) measurement")
@@ -124,9 +126,11 @@ def main():
             pe = pb
     else:
         pb, pe = 0, 0
+    if a.precision == "fp16":
+        a.mode = "stream"
     thr = (T + 1) if a.mode == "stream" else 0
     eng = Convolution("bench", a.fft_size, max_batch=T, device=local, part_begin=pb,
-                      part_end=pe if world > 1 else 0, stream_threshold=min(thr, 4096))
+                      part_end=pe if world > 1 else 0, stream_threshold=min(thr, 4096), precision=a.precision)
     if world > 1 and pe == pb:
         raise SystemExit("empty shard; use fewer ranks")
     # two distinct IRs (seed 5678 + path): in1 -> (L,R) through IR 0, in2 -> (L,R) through IR 1,
@@ -273,7 +277,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if a.precision == "fp32" else "f16 storage, f32 accumulate",
             "data": "synthetic",
             "config": {
                 "workload": f"stereo 44.1 kHz, 256-frame blocks, {a.taps}-tap IR ({P} partitions, N_ref {a.fft_size}), "

@@ -36,7 +36,8 @@ class McConfig(C.Structure):
         ("part_begin", C.c_uint32),
         ("part_end", C.c_uint32),
         ("stream_threshold", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("precision", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 

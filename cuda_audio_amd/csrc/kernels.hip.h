@@ -21,8 +21,11 @@
 // a select CC the outgoing IR and the incoming IR are two voices whose
 // coefficients follow the reference's recurrence exactly.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "fft512.hip.h"
 
@@ -32,6 +35,21 @@
 #define MC_MAXV 3    // voices (IR pairs) that may sound at once
 #define FWD_TILE 8   // blocks per workgroup of the forward / inverse transform kernels (2 per wave)
 #define FWD_TILE_LOG2 3
+
+// fp16 storage of a spectrum entry: four halves {a.re, a.im, b.re, b.im} in 8 bytes
+__device__ __forceinline__ uint2 pack_half4(float4 v, float scale) {
+    const __half2 lo = __floats2half2_rn(v.x * scale, v.y * scale), hi = __floats2half2_rn(v.z * scale, v.w * scale);
+    uint2 r;
+    r.x = *reinterpret_cast<const unsigned*>(&lo);
+    r.y = *reinterpret_cast<const unsigned*>(&hi);
+    return r;
+}
+__device__ __forceinline__ float4 unpack_half4(uint2 r) {
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
+    const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+#define FDL16_SCALE 16.0f  // |X| <= 256 for |x| <= 1: 4096 in half, well inside its range
 
 // Per-block parameters computed on the host in double (cross-fade recurrence, pans, levels)
 struct BlockParams {
@@ -61,7 +79,8 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
                                              const BlockParams* __restrict__ ptab, int pstride,
                                              float4* __restrict__ sums,      // [T] raw {S1,S2,A1,A2} or null
                                              float4* __restrict__ slotgain,  // [MC_MAXV][ring] or null
-                                             const float2* __restrict__ g_tw) {
+                                             const float2* __restrict__ g_tw,
+                                             uint2* __restrict__ fdl16 = nullptr) {  // fp16 mirror of the delay line or null
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
@@ -115,8 +134,17 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
-        if (t < T) fdl[(size_t)k * ring + ((slot0 + t) & (ring - 1))] = s_tile[k][tb];
+        if (t < T) {
+            const size_t at = (size_t)k * ring + ((slot0 + t) & (ring - 1));
+            fdl[at] = s_tile[k][tb];
+            if (fdl16) fdl16[at] = pack_half4(s_tile[k][tb], FDL16_SCALE);
+        }
     }
+}
+
+// fp32 -> scaled fp16 copy of an IR's spectra (load time)
+__global__ __launch_bounds__(256) void k_to_half(const float4* __restrict__ src, uint2* __restrict__ dst, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = pack_half4(src[i], scale);
 }
 
 // ---------------------------------------------------------------------------
@@ -360,32 +388,49 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
 // ---------------------------------------------------------------------------
 #define STREAM_U 4  // partitions per lane and loop trip
 
-template <bool UNIFORM, int NT>
-__global__ __launch_bounds__(NT) void k_mac_stream(const float4* __restrict__ H0, const float4* __restrict__ H1,
+// HALF: spectra and delay line are read as scaled half4 (8 B per entry, half the bytes), products and sums
+// stay fp32; `inv` = 1 / (scale of IR 0 * FDL scale), 1 / (scale of IR 1 * FDL scale) undoes the scaling.
+template <bool UNIFORM, int NT, bool HALF>
+__global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v, const void* __restrict__ H1v,
                                                    int pstride_ir, int p_begin, int p_end, int chunk,
-                                                   const float4* __restrict__ fdl, const float4* __restrict__ slotgain,
+                                                   const void* __restrict__ fdlv, const float4* __restrict__ slotgain,
                                                    int ring, int slot0, float4* __restrict__ part, int nsum, int ch_off,
-                                                   float4 ugain) {
+                                                   float4 ugain, float2 inv) {
+    typedef typename std::conditional<HALF, uint2, float4>::type ST;
     const int bin = blockIdx.x, ch = blockIdx.y, t = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float4* H0k = H0 + (size_t)bin * pstride_ir;
-    const float4* H1k = H1 + (size_t)bin * pstride_ir;
-    const float4* fk = fdl + (size_t)bin * ring;
+    const ST* H0k = reinterpret_cast<const ST*>(H0v) + (size_t)bin * pstride_ir;
+    const ST* H1k = reinterpret_cast<const ST*>(H1v) + (size_t)bin * pstride_ir;
+    const ST* fk = reinterpret_cast<const ST*>(fdlv) + (size_t)bin * ring;
     const int lo = p_begin + ch * chunk, hi = min(lo + chunk, p_end);
     const int st = slot0 + t;
     float2 yl = make_float2(0.f, 0.f), yr = make_float2(0.f, 0.f);
     const bool packed = (bin == 0);
     for (int p0 = lo + (int)threadIdx.x; p0 < hi; p0 += NT * STREAM_U) {
         float4 x[STREAM_U], g[STREAM_U], h0[STREAM_U], h1[STREAM_U];
+        ST xs[STREAM_U], h0s[STREAM_U], h1s[STREAM_U];
 #pragma unroll
         for (int u = 0; u < STREAM_U; u++) {
             const int p = min(p0 + NT * u, hi - 1);  // clamped: the load is always in range, masked below
             const int slot = (st - p) & (ring - 1);
-            x[u] = fk[slot];
+            xs[u] = fk[slot];
             g[u] = ugain;
             if (!UNIFORM) g[u] = slotgain[slot];
-            h0[u] = H0k[p];
-            h1[u] = H1k[p];
+            h0s[u] = H0k[p];
+            h1s[u] = H1k[p];
+        }
+#pragma unroll
+        for (int u = 0; u < STREAM_U; u++) {
+            if constexpr (HALF) {
+                x[u] = unpack_half4(xs[u]);
+                h0[u] = unpack_half4(h0s[u]);
+                h1[u] = unpack_half4(h1s[u]);
+                g[u] = make_float4(g[u].x * inv.x, g[u].y * inv.y, g[u].z * inv.x, g[u].w * inv.y);
+            } else {
+                x[u] = xs[u];
+                h0[u] = h0s[u];
+                h1[u] = h1s[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < STREAM_U; u++) {
@@ -782,7 +827,8 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                                                int seg0, float* __restrict__ wet, int wr, double* __restrict__ cring,
                                                int rc, VoiceSums vs, double inv_n, int compat, int64_t tabs0,
                                                int64_t predelay, int64_t n_ref, float* __restrict__ outL,
-                                               float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td) {
+                                               float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td,
+                                               uint2* __restrict__ fdl16) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
     __shared__ float4 s_x[MC_NB];  // raw spectra of the new block {X1, X2}
@@ -821,6 +867,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             const float4 xs = make_float4(x1.x, x1.y, x2.x, x2.y);
             s_x[k] = xs;
             fdl[(size_t)k * ring + slot0] = xs;
+            if (fdl16) fdl16[(size_t)k * ring + slot0] = pack_half4(xs, FDL16_SCALE);
         }
         if (lane < MC_MAXV)
             slotgain[(size_t)lane * ring + slot0] = make_float4(bp.g[lane][0], bp.g[lane][1], bp.g[lane][2], bp.g[lane][3]);

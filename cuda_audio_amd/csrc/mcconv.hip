@@ -58,6 +58,8 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 struct IrEntry {
     float4* d_H = nullptr;
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
+    uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
+    float scale16 = 1.f;
     uint64_t taps = 0;
     int P = 0;
     double sums[4] = {0, 0, 0, 0};
@@ -77,6 +79,8 @@ struct mc_engine {
     IrEntry irs[kMaxIrs];
     int nirs = 0;
 
+    uint2* d_fdl16 = nullptr;  // fp16 mirror of the delay line (precision = fp16)
+    bool half = false;
     float4 *d_fdl = nullptr, *d_slotgain = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
     float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
@@ -179,6 +183,7 @@ int drain_kernel_events(mc_engine* e) {
 int zero_state(mc_engine* e) {
     if (e->side) HIP_TRY(hipStreamSynchronize(e->side));
     HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
+    if (e->d_fdl16) HIP_TRY(hipMemsetAsync(e->d_fdl16, 0, sizeof(uint2) * (size_t)MC_NB * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_slotgain, 0, sizeof(float4) * (size_t)MC_MAXV * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_wet, 0, sizeof(float) * 2 * (size_t)e->wr, e->stream));
@@ -425,14 +430,27 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
     const int chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
     const dim3 grid(MC_NB, e->nchunk, T);
     const float4* sg = e->d_slotgain + (size_t)a.v * e->ring;
-#define MC_LAUNCH_STREAM(U, NT)                                                                                             \
-    hipLaunchKernelGGL((k_mac_stream<U, NT>), grid, dim3(NT), 0, e->stream, a.ir0->d_H, a.ir1->d_H, e->Pstride, p_lo, p_hi, \
-                       chunk, e->d_fdl, sg, e->ring, slot0, e->d_part, nsum, ch_off, a.ugain)
+    const bool half = e->half && a.ir0->d_H16 && a.ir1->d_H16;
+    const void* h0 = half ? (const void*)a.ir0->d_H16 : (const void*)a.ir0->d_H;
+    const void* h1 = half ? (const void*)a.ir1->d_H16 : (const void*)a.ir1->d_H;
+    const void* fd = half ? (const void*)e->d_fdl16 : (const void*)e->d_fdl;
+    const float2 inv = make_float2(1.0f / (a.ir0->scale16 * FDL16_SCALE), 1.0f / (a.ir1->scale16 * FDL16_SCALE));
+#define MC_LAUNCH_STREAM(U, NT, H)                                                                                        \
+    hipLaunchKernelGGL((k_mac_stream<U, NT, H>), grid, dim3(NT), 0, e->stream, h0, h1, e->Pstride, p_lo, p_hi, chunk, fd, sg, \
+                       e->ring, slot0, e->d_part, nsum, ch_off, a.ugain, inv)
+#define MC_LAUNCH_STREAM_H(U, NT) \
+    do {                          \
+        if (half)                 \
+            MC_LAUNCH_STREAM(U, NT, true); \
+        else                      \
+            MC_LAUNCH_STREAM(U, NT, false); \
+    } while (0)
     if (nt == 512) {
-        if (a.uniform) MC_LAUNCH_STREAM(true, 512); else MC_LAUNCH_STREAM(false, 512);
+        if (a.uniform) MC_LAUNCH_STREAM_H(true, 512); else MC_LAUNCH_STREAM_H(false, 512);
     } else {
-        if (a.uniform) MC_LAUNCH_STREAM(true, 256); else MC_LAUNCH_STREAM(false, 256);
+        if (a.uniform) MC_LAUNCH_STREAM_H(true, 256); else MC_LAUNCH_STREAM_H(false, 256);
     }
+#undef MC_LAUNCH_STREAM_H
 #undef MC_LAUNCH_STREAM
 }
 
@@ -456,7 +474,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
-                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw);
+                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16);
     // Q1/Q2 prefix sums need only k_fwd's block sums: fork them to the side stream so they run beside the MAC
     HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
@@ -464,7 +482,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                        1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)st.ctx.t0);
     HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], e->side));
 
-    const bool resident = T >= e->stream_threshold;
+    const bool resident = T >= e->stream_threshold && !e->half;
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
     if (e->ktiming) {
         if (e->kev_n == kEvPool) {
@@ -654,7 +672,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                        e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, seg0, e->d_wet, e->wr,
                        e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,
                        (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay));
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
@@ -764,6 +782,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 32;
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
+    e->half = cfg->precision == 1;
+    if (e->half) e->stream_threshold = e->Tmax + 1;  // the fp16 MAC is the streaming sweep
     e->Tstream = std::min(e->Tmax, std::max(1, e->stream_threshold - 1));
 
 #define ENG_TRY(expr)                                                                                     \
@@ -784,6 +804,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     e->stream = e->own_stream;
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
+    if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
     ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * e->Tmax));
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
@@ -832,8 +853,11 @@ void mc_destroy(mc_engine* e) {
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
+    for (int i = 0; i < kMaxIrs; i++)
+        if (e->irs[i].d_H16) (void)hipFree(e->irs[i].d_H16);
     (void)hipFree(e->d_fdl);
     (void)hipFree(e->d_slotgain);
+    (void)hipFree(e->d_fdl16);
     (void)hipFree(e->d_Y);
     (void)hipFree(e->d_part);
     (void)hipFree(e->d_sums);
@@ -907,6 +931,22 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     }
     if (ir.d_h) (void)hipFree(ir.d_h);
     ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
+    if (e->half) {
+        // scaled fp16 copy: one power-of-two scale per IR puts the largest bin near 2^13 (half max 65504);
+        // a 60 dB decay then still sits ~2^3 above the smallest normal half
+        const size_t nel = (size_t)MC_NB * e->Pstride;
+        std::vector<float> host(nel * 4);
+        HIP_TRY(hipMemcpy(host.data(), ir.d_H, sizeof(float4) * nel, hipMemcpyDeviceToHost));
+        float mx = 0.f;
+        for (float v : host) mx = std::max(mx, std::fabs(v));
+        int ex = 0;
+        if (mx > 0.f) std::frexp(mx, &ex);
+        ir.scale16 = std::ldexp(1.0f, 13 - ex);
+        if (!ir.d_H16) HIP_TRY(hipMalloc(&ir.d_H16, sizeof(uint2) * nel));
+        hipLaunchKernelGGL(k_to_half, dim3(1024), dim3(256), 0, e->stream, ir.d_H, ir.d_H16, nel, ir.scale16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     double s[4] = {0, 0, 0, 0};
     for (uint64_t m = 0; m < n; m++) {
         const double sg = (m & 1) ? -1.0 : 1.0;
@@ -1080,7 +1120,7 @@ uint64_t mc_algorithmic_bytes_per_block(const mc_engine* e) {
     const IrEntry& b = e->irs[e->cc[1].select % kMaxIrs];
     int P = std::max(a.P, b.P);
     if (e->cfg.part_end) P = std::max(0, std::min<int>(P, (int)e->cfg.part_end) - (int)e->cfg.part_begin);
-    return (uint64_t)(4 + 2) * (uint64_t)P * MC_NB * 8ull;
+    return (uint64_t)(4 + 2) * (uint64_t)P * MC_NB * (e->half ? 4ull : 8ull);
 }
 
 uint64_t mc_blocks_processed(const mc_engine* e) { return e ? e->t_abs : 0; }

@@ -80,7 +80,7 @@ class CC:
 
 class Convolution:
     def __init__(self, name="Conv", fftSize=CONV_DEFAULT_FFTSIZE, *, max_batch=256, device=-1, compat=True,
-                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0):
+                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32"):
         self.name = name
         self._L = _lib.load()
         cfg = McConfig()
@@ -92,6 +92,7 @@ class Convolution:
         cfg.part_begin, cfg.part_end = part_begin, part_end
         cfg.max_partitions = max_partitions
         cfg.stream_threshold = stream_threshold
+        cfg.precision = {"fp32": 0, "fp16": 1}[precision]
         h = C.c_void_p()
         check(self._L.mc_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -66,7 +66,9 @@ typedef struct {
     uint32_t part_end;      /* engine; 0,0 = all partitions (single GPU) */
     uint32_t stream_threshold; /* batches shorter than this use the streaming MAC kernel
                                (0 = default) */
-    uint32_t reserved[5];
+    uint32_t precision;     /* 0 = fp32 spectra; 1 = fp16 storage of IR spectra and delay line for the
+                               partition sweep (fp32 products and sums; streaming kernel only) */
+    uint32_t reserved[4];
 } mc_config;
 
 /* mirrors Convolution::CC::value (conv.h:38-49); same defaults via mc_default_params */
