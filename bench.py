@@ -57,34 +57,49 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ir, ir_b, x, seconds):
-    """oracle Cpu32 (float32 OpenMP partitioned overlap-save) on a bounded sample of the same workload."""
+def cpu_threads():
+    """Threads for the CPU baseline: the cgroup CPU quota of this box when there is one (a GPU box shows all
+    host CPUs but is throttled to its share), else what OpenMP reports."""
     import oracle
 
-    threads = oracle.max_threads()
+    n = oracle.max_threads()
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(ir, ir_b, x, seconds):
+    """oracle Cpu32 (float32 OpenMP partitioned overlap-save) on a bounded sample of the same workload:
+    chunks of 128 blocks until `seconds` of wall clock have passed."""
+    import oracle
+
+    threads = cpu_threads()
     eng = oracle.Cpu32(ir, ir_b)
     g = np.array([0.5, 0.5, 0.5, 0.5], np.float32)
-    n_cal = 48
-    eng.process(x[0, : n_cal * BLOCK], x[1, : n_cal * BLOCK], g, g)  # warm (fills caches / delay line)
-    t0 = time.perf_counter()
-    eng.process(x[0, : n_cal * BLOCK], x[1, : n_cal * BLOCK], g, g)
-    per = (time.perf_counter() - t0) / n_cal
-    avail = x.shape[1] // BLOCK
-    nblk = int(max(n_cal, seconds / max(per, 1e-6)))
+    chunk, avail = 128, x.shape[1] // BLOCK
+    eng.process(x[0, : chunk * BLOCK], x[1, : chunk * BLOCK], g, g, threads)  # warm-up, untimed
     t0 = time.perf_counter()
     done = 0
-    while done < nblk:  # the sample repeats the same input batches; state (delay line) carries over
-        n = min(avail, nblk - done)
-        eng.process(x[0, : n * BLOCK], x[1, : n * BLOCK], g, g)
-        done += n
+    while time.perf_counter() - t0 < seconds:
+        o = (done % max(avail - chunk, 1))
+        eng.process(x[0, o * BLOCK : (o + chunk) * BLOCK], x[1, o * BLOCK : (o + chunk) * BLOCK], g, g, threads)
+        done += chunk
     dt = time.perf_counter() - t0
     eng.close()
     return {
-        "value": round(nblk * BLOCK / FS / dt, 3),
+        "value": round(done * BLOCK / FS / dt, 3),
         "unit": "x realtime",
         "cores": threads,
         "kind": "port",
-        "sample": f"{nblk} blocks ({nblk * BLOCK / FS:.1f} s of audio) of the same stereo/{ir.shape[0]}-tap workload, "
+        "sample": f"{done} blocks ({done * BLOCK / FS:.1f} s of audio) of the same stereo/{ir.shape[0]}-tap workload, "
                   f"oracle/oracle.c orc_cpu32 (own radix-2 FFT, OpenMP over bins), {dt:.1f} s wall",
     }
 

@@ -598,31 +598,27 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
     }
 }
 
-#define CORR_NT 1024      // one workgroup
-#define CORR_PER_MAX 4    // blocks per thread: T <= 1024 * 4
+#define CORR_NT 256  // one small workgroup: few registers, so it runs beside the MAC waves on the side stream
 
 __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
                                                   int pstride, int T, VoiceSums vs, double inv_n, int compat,
                                                   double* __restrict__ cring, int rc, int64_t tabs0) {
     // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc).
+    // Thread tid owns the consecutive blocks tid*per .. ; pass 1 sums their terms, a 256-wide scan joins
+    // the threads, pass 2 recomputes the terms and writes the running sums (nothing is kept in registers
+    // between the passes: the kernel must stay small enough to co-reside with the partition sweep).
     __shared__ double s_part[CORR_NT][4];
     const int tid = threadIdx.x;
     const int per = (T + CORR_NT - 1) / CORR_NT;
-    double loc[CORR_PER_MAX][4];
     double run[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < CORR_PER_MAX; j++) {
-        const int t = tid * per + j;
-        const bool ok = j < per && t < T && compat;
-        const int tc = min(t, T - 1);  // clamped, unconditional loads; masked by select
-        const float4 v = sums[tc];
-        const BlockParams* bp = ptab + (int64_t)tc * pstride;
-        double d[4];
-        corr_terms(v, *bp, vs, inv_n, d);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            run[c] += ok ? d[c] : 0.0;
-            loc[j][c] = run[c];
+    if (compat) {
+        for (int j = 0; j < per; j++) {
+            const int t = tid * per + j;
+            if (t < T) {
+                double d[4];
+                corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
+                for (int c = 0; c < 4; c++) run[c] += d[c];
+            }
         }
     }
     for (int c = 0; c < 4; c++) s_part[tid][c] = run[c];
@@ -641,13 +637,16 @@ __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sum
         for (int c = 0; c < 4; c++) base[c] = p[c];
     }
     for (int c = 0; c < 4; c++) base[c] += s_part[tid][c] - run[c];  // exclusive prefix of this thread
-#pragma unroll
-    for (int j = 0; j < CORR_PER_MAX; j++) {
+    for (int j = 0; j < per; j++) {
         const int t = tid * per + j;
-        if (j < per && t < T) {
+        if (t < T) {
+            if (compat) {
+                double d[4];
+                corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
+                for (int c = 0; c < 4; c++) base[c] += d[c];
+            }
             double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
-#pragma unroll
-            for (int c = 0; c < 4; c++) o[c] = base[c] + loc[j][c];
+            for (int c = 0; c < 4; c++) o[c] = base[c];
         }
     }
 }
@@ -689,7 +688,9 @@ __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64
         const int64_t s = tau - pd - (tb << 8);  // position inside block tb's contribution, >= n_ref - pd
         const int64_t rel = tb - (tau0 >> 8);
         const int64_t base = tb << 8;
-        for (int vi = 0; vi < td.nv; vi++) {
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+            if (vi >= td.nv) break;
             float4 g;
             if (rel >= 0 && rel < T) {
                 const float* gv = ptab[rel * pstride].g[vi];
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
     __shared__ double s_c[4];
     __shared__ float4 s_sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BlockParams bp = ptab[0];
+    const BlockParams& bp = ptab[0];  // read through global memory: a local copy indexed at run time would live in scratch
     load_twiddles(s_tw, g_tw);
     s_in[0][tid] = in1[tid];
     s_in[1][tid] = in2[tid];
@@ -890,8 +891,10 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         const int k = tid;
         const float4 x = s_x[k];
         float4 y = s_y[k];
-        for (int vi = 0; vi < vset.n; vi++) {
-            const float* g = bp.g[vset.vid[vi]];
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {  // constant indices: runtime-indexed kernel-argument arrays go to scratch
+            if (vi >= vset.n) break;
+            const float* g = ptab->g[vset.vid[vi]];
             const float4 h0 = vset.H0[vi][(size_t)k * pstride_ir], h1 = vset.H1[vi][(size_t)k * pstride_ir];
             float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
             if (k == 0) {

@@ -76,6 +76,8 @@ struct mc_engine {
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
     int stream_threshold = 0;
     int stream_nt = 256;
+    bool corr_main = true;  // MCCONV_CORR_SIDE=1 moves the Q1/Q2 prefix sums to a side stream beside the MAC
+                            // (measured: no difference in step time, so the simpler single-stream order is the default)
     IrEntry irs[kMaxIrs];
     int nirs = 0;
 
@@ -475,12 +477,15 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16);
-    // Q1/Q2 prefix sums need only k_fwd's block sums: fork them to the side stream so they run beside the MAC
-    HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
-    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
-    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->side, d_sums, d_ptab, pstride, T, st.ctx.vs,
+    // Q1/Q2 prefix sums need only k_fwd's block sums (optionally forked to the side stream)
+    hipStream_t cs = e->corr_main ? e->stream : e->side;
+    if (!e->corr_main) {
+        HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
+    }
+    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, cs, d_sums, d_ptab, pstride, T, st.ctx.vs,
                        1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)st.ctx.t0);
-    HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], e->side));
+    HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], cs));
 
     const bool resident = T >= e->stream_threshold && !e->half;
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
@@ -826,6 +831,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
+    if (std::getenv("MCCONV_CORR_SIDE")) e->corr_main = false;
     ENG_TRY(hipEventCreate(&e->ev0));
     ENG_TRY(hipEventCreate(&e->ev1));
     {
