@@ -611,3 +611,46 @@ def test_config5_fp16_full_length_30s(gpu_lib):
     tail = slice((P - 200) * 256, P * 256)  # the -60 dB end of the IR keeps its relative accuracy (per-IR scaling)
     assert rms(y[:, tail] - want[:, tail]) <= 4 * FP16_REL_TOL * rms(want[:, tail])
     c.close()
+
+
+def test_error_behaviour_and_edge_cases(oracle_mod, gpu_lib):
+    """Boundary behaviour of the C ABI: wrong period length, missing IR, oversize batch, oversize IR capacity,
+    IR longer than N_ref - 1024 (truncated like conv.cu:239), reset."""
+    from cuda_audio_amd._lib import McError
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    c = _conv(fftSize=4096, max_batch=8)
+    x = make_input(16 * 256)
+    with pytest.raises(McError) as ei:  # no IR loaded yet
+        c.onProcess(x[0, :256], x[1, :256])
+    assert ei.value.code == -3
+    ir = make_ir(5000, seed=3, norm=0.05)  # longer than 4096 - 1024: truncated to 3072 taps / 12 partitions
+    c.prepare(0, ir)
+    assert c.ir_info(0)["taps"] == 3072 and c.ir_info(0)["partitions"] == 12
+    with pytest.raises(McError) as ei:  # the engine is built for 256-frame periods (the reference mis-computes > 1024)
+        c.onProcess(x[0, :128], x[1, :128])
+    assert ei.value.code == -1
+    with pytest.raises(McError):
+        c.process_device(1, 1, 1, 1, 9)  # more blocks than max_batch
+    c.cc[0].value.select = 7
+    with pytest.raises(McError):
+        c.onProcess(x[0, :256], x[1, :256])  # selected IR not loaded
+    c.cc[0].value.select = 0
+    ref = oracle_mod.RefCompat(4096, True)
+    ref.prepare(0, ir)
+    want = ref.process(x[0], x[1])
+    got = c.process(x[0], x[1])
+    assert rms(got - want) <= RMS_TOL
+    # reset returns to the cold state: same input, same output again
+    c.reset()
+    assert c.blocks_processed() == 0
+    assert rms(c.process(x[0], x[1]) - want) <= RMS_TOL
+    # silence in, silence out (no DC offsets, no NaNs)
+    c.reset()
+    z = np.zeros(8 * 256, np.float32)
+    out = c.process(z, z)
+    assert np.all(out == 0.0)
+    c.close()
+    with pytest.raises(McError):  # IR needs more partitions than the engine was sized for
+        d = _conv(fftSize=8192, max_batch=4, max_partitions=4)
+        d.prepare(0, make_ir(3000, seed=1))
