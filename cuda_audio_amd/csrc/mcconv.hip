@@ -220,10 +220,17 @@ int voice_slot_for(mc_engine* e, int i, int ir, uint64_t block) {
             vs[v].ir = ir;
             return v;
         }
-    // more than MC_MAXV IRs cross-fading within one IR length: drop the quietest (documented limit)
+    // more than MC_MAXV IRs sounding within one IR length: the quietest one is cut off (documented limit).
+    // Its rows of the gain tables are cleared so that its old slots can never be played through the new IR.
     int q = 0;
     for (int v = 1; v < MC_MAXV; v++)
         if (std::fabs(vs[v].coef) < std::fabs(vs[q].coef)) q = v;
+    const int other = e->voice[1 - i][q].ir;
+    if (other < 0 || e->voice[1 - i][q].coef == 0.0) {
+        (void)hipMemsetAsync(e->d_slotgain + (size_t)q * e->ring, 0, sizeof(float4) * (size_t)e->ring, e->stream);
+        (void)hipMemsetAsync(e->d_gring + (size_t)q * e->rc, 0, sizeof(float4) * (size_t)e->rc, e->stream);
+        e->voice_ever[q] = false;
+    }
     vs[q] = mc_engine::VoiceSlot();
     vs[q].ir = ir;
     return q;
@@ -250,7 +257,7 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
                 s.coef += (target - s.coef) / div;
                 // settle: the recurrence converges geometrically; snap once the distance is below double
                 // resolution of the reference's float spectra (keeps steady-state tables bit-identical)
-                if (std::fabs(target - s.coef) <= 1e-300 + 4e-16 * std::fabs(target) || (target == 0.0 && std::fabs(s.coef) < 1e-30))
+                if (std::fabs(target - s.coef) <= 1e-300 + 4e-16 * std::fabs(target) || (target == 0.0 && std::fabs(s.coef) < 1e-14))
                     s.coef = target;
             }
             if (cc[i].vsteps > 0) cc[i].vsteps--;
