@@ -791,7 +791,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
     e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
-    e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 32;
+    e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 96;  // measured crossover ~80 blocks (scripts/sweep_T.sh)
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
     e->half = cfg->precision == 1;
