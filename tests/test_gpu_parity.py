@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 def _conv(**kw):
     from cuda_audio_amd.engine import Convolution
 
+    # tests keep batches short for the oracle's sake: lower the stream/resident switch-over (default 96 blocks)
+    # so that batches of >= 8 blocks run the resident kernel and shorter ones / single periods the streaming one
+    kw.setdefault("stream_threshold", 8)
     return Convolution("test", **kw)
 
 

@@ -123,3 +123,37 @@ def test_convolution_class_through_fake_jack(host_built, oracle_mod, tmp_path):
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e}"
     assert "avg_runtime_ms" in res.stdout
+
+
+@pytest.mark.gpu
+def test_main_flow_with_settings_file(host_built, tmp_path):
+    """mcconv_host = the reference's main() order (main.cu:18-116): selectGpu, settings.txt, one Convolution per
+    channel pair, MIDI mapping + initial values, IR bank from an index file, start, connect, run, avg runtime.
+    Two pairs (conv.count 4) to exercise several instances on one GPU (main.cu:31-39)."""
+    from cuda_audio_amd.synth import make_ir
+
+    wavs = []
+    for j, bits in enumerate((16, 24, 16)):
+        w = tmp_path / f"ir{j}.wav"
+        _write_wav(str(w), make_ir(3000 + 700 * j, seed=70 + j, norm=0.05), bits)
+        wavs.append(str(w))
+    index = tmp_path / "all.index"
+    index.write_text("\n".join(wavs) + "\n")
+    lines = ["# generated by the test", "conv.count 4"]
+    for i in range(4):
+        lines += [f"conv[{i}].fftSize 16384", f"conv[{i}].maxPredelay 8192", f"conv[{i}].index {index}",
+                  f"conv[{i}].input system:capture_{i + 1}", f"conv[{i}].output system:playback_{i + 1}",
+                  f"conv[{i}].cc.device hw:2,0", f"conv[{i}].cc.message 176", f"conv[{i}].cc.select 21",
+                  f"conv[{i}].cc.predelay 22", f"conv[{i}].cc.dry 23", f"conv[{i}].cc.wet 24", f"conv[{i}].cc.speed 25",
+                  f"conv[{i}].cc.panDry {26 + i % 2}", f"conv[{i}].cc.panWet {26 + i % 2}", f"conv[{i}].cc.level 28",
+                  f"conv[{i}].value.select {i % 3}", f"conv[{i}].value.predelay 1024", f"conv[{i}].value.dry 0.5",
+                  f"conv[{i}].value.wet 0.5", f"conv[{i}].value.speed 100", f"conv[{i}].value.panDry 0",
+                  f"conv[{i}].value.panWet 0", f"conv[{i}].value.level 1.0"]
+    settings = tmp_path / "settings.txt"
+    settings.write_text("\n".join(lines) + "\n")
+    res = subprocess.run([os.path.join(HOST, "mcconv_host"), "--settings", str(settings), "--periods", "60"],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = res.stdout + res.stderr
+    assert out.count("Average convolution runtime") == 2
+    assert "Selected GPU" in out
