@@ -122,6 +122,9 @@ def main():
     dev = torch.device("cuda", local)
     sharded = world > 1 or a.force_sharded
     if sharded:
+        # RCCL prints its version banner to stdout at NCCL_DEBUG=VERSION; the contract is ONE JSON line on stdout
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO") and not os.environ.get("MCCONV_KEEP_NCCL_DEBUG"):
+            os.environ["NCCL_DEBUG"] = "WARN"
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -257,6 +260,17 @@ def main():
         ks1 = eng.kernel_stats()
         eng.enable_kernel_timing(False)
         k_ms = ks1["total_ms"] / max(ks1["launches"], 1)
+        # rocprofv3 duration of the same kernel in the same path, from the committed profile of this round
+        prof_us = None
+        try:
+            import csv
+
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_jack_kernel_stats.csv"))))
+            tot = sum(float(r["TotalDurationNs"]) for r in rows if "k_mac_stream" in r["Name"])
+            cnt = sum(int(r["Calls"]) for r in rows if "k_mac_stream" in r["Name"])
+            prof_us = tot / cnt / 1e3 if cnt else None
+        except Exception:
+            prof_us = None
         latency = {
             "us_per_block_wall": round(lat * 1e6, 2),
             "rtf": round(BLOCK / FS / lat, 1),
@@ -265,7 +279,11 @@ def main():
             "mac_kernel_us_event_bracketed": round(k_ms * 1e3, 2),
             "mac_achieved_GBps": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
             "mac_frac_of_hbm_peak": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
-            "note": "event-bracketed single launches include ~2 us of event overhead; rocprofv3 durations are in profiles/",
+            "mac_kernel_us_rocprofv3": round(prof_us, 2) if prof_us else None,
+            "mac_achieved_GBps_rocprofv3": round(alg_bytes / (prof_us * 1e-6) / 1e9, 1) if prof_us else None,
+            "mac_frac_of_hbm_peak_rocprofv3": round(alg_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None,
+            "note": "event-bracketed single launches include ~3 us of event overhead; the rocprofv3 figure is the "
+                    "kernel's average duration in profiles/r1_jack_kernel_stats.csv (same path, same IRs)",
         }
 
     cpu = None
