@@ -123,8 +123,8 @@ def main():
     sharded = world > 1 or a.force_sharded
     if sharded:
         # RCCL prints its version banner to stdout at NCCL_DEBUG=VERSION; the contract is ONE JSON line on stdout
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO") and not os.environ.get("MCCONV_KEEP_NCCL_DEBUG"):
-            os.environ["NCCL_DEBUG"] = "WARN"
+        if not os.environ.get("MCCONV_KEEP_NCCL_DEBUG"):
+            os.environ.pop("NCCL_DEBUG", None)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
