@@ -71,13 +71,9 @@ struct mc_engine {
     mc_config cfg;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side = nullptr;  // Q1/Q2 prefix sums run here, concurrently with the MAC
-    hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_corr[2] = {nullptr, nullptr};
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
     int stream_threshold = 0;
     int stream_nt = 256;
-    bool corr_main = true;  // MCCONV_CORR_SIDE=1 moves the Q1/Q2 prefix sums to a side stream beside the MAC
-                            // (measured: no difference in step time, so the simpler single-stream order is the default)
     IrEntry irs[kMaxIrs];
     int nirs = 0;
 
@@ -183,7 +179,6 @@ int drain_kernel_events(mc_engine* e) {
 }
 
 int zero_state(mc_engine* e) {
-    if (e->side) HIP_TRY(hipStreamSynchronize(e->side));
     HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
     if (e->d_fdl16) HIP_TRY(hipMemsetAsync(e->d_fdl16, 0, sizeof(uint2) * (size_t)MC_NB * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_slotgain, 0, sizeof(float4) * (size_t)MC_MAXV * e->ring, e->stream));
@@ -484,16 +479,6 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16);
-    // Q1/Q2 prefix sums need only k_fwd's block sums (optionally forked to the side stream)
-    hipStream_t cs = e->corr_main ? e->stream : e->side;
-    if (!e->corr_main) {
-        HIP_TRY(hipEventRecord(e->ev_fwd[st.ctx.slot], e->stream));
-        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fwd[st.ctx.slot], 0));
-    }
-    hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, cs, d_sums, d_ptab, pstride, T, st.ctx.vs,
-                       1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)st.ctx.t0);
-    HIP_TRY(hipEventRecord(e->ev_corr[st.ctx.slot], cs));
-
     const bool resident = T >= e->stream_threshold && !e->half;
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
     if (e->ktiming) {
@@ -580,11 +565,12 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
     if (ctx.T != T) return fail(MC_ERR_ARG, "finish of %d blocks but the pending batch has %d", T, ctx.T);
     e->pipe_head = (e->pipe_head + 1) % kPipe;
     e->pipe_count--;
-    // join the side stream (Q1/Q2 prefix sums of this batch) — also when retiring without output, so that
-    // the batch's parameter slot is never rewritten while the side stream still reads it
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_corr[ctx.slot], 0));
     if (d_outL && d_outR) {
         const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
+        const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
+        // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
+        hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
+                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0);
         hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
                            e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
                            (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
@@ -809,11 +795,6 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     } while (0)
 
     ENG_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-    ENG_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        ENG_TRY(hipEventCreateWithFlags(&e->ev_fwd[i], hipEventDisableTiming));
-        ENG_TRY(hipEventCreateWithFlags(&e->ev_corr[i], hipEventDisableTiming));
-    }
     e->stream = e->own_stream;
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
@@ -838,7 +819,6 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
-    if (std::getenv("MCCONV_CORR_SIDE")) e->corr_main = false;
     ENG_TRY(hipEventCreate(&e->ev0));
     ENG_TRY(hipEventCreate(&e->ev1));
     {
@@ -897,14 +877,6 @@ void mc_destroy(mc_engine* e) {
             (void)hipEventDestroy(e->kev[i][0]);
             (void)hipEventDestroy(e->kev[i][1]);
         }
-    for (int i = 0; i < 2; i++) {
-        if (e->ev_fwd[i]) (void)hipEventDestroy(e->ev_fwd[i]);
-        if (e->ev_corr[i]) (void)hipEventDestroy(e->ev_corr[i]);
-    }
-    if (e->side) {
-        (void)hipStreamSynchronize(e->side);
-        (void)hipStreamDestroy(e->side);
-    }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }

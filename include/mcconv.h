@@ -125,7 +125,8 @@ int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2
  * Up to two batches may be between their partial and their finish (finishes
  * retire batches in order), so the reduce of batch k can overlap the MAC of
  * batch k+1.  A rank that does not need the output (non-root of a reduce)
- * passes NULL for d_wet_sum, d_outL and d_outR: the batch is retired, nothing runs. */
+ * passes NULL for d_wet_sum, d_outL and d_outR: the batch is retired, nothing runs (such a shard keeps no
+ * Q1/Q2 history, so an engine should either always or never finish with output). */
 int mc_partial_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_partial, uint64_t nblocks);
 int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, const float *d_wet_sum,
                            float *d_outL, float *d_outR, uint64_t nblocks);
