@@ -278,11 +278,18 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
                                                       const float4* __restrict__ fdl, int ring, int slot0, int T,
                                                       float4 ugain,                         // SLOTGAIN = false
                                                       const float4* __restrict__ slotgain,  // SLOTGAIN = true: [ring]
-                                                      float4* __restrict__ Y, int tcap, int accumulate) {
+                                                      float4* __restrict__ Y, int tcap, int accumulate,
+                                                      int psplit, int pchunk) {
+    // grid = 256 bins x tiles x psplit: short batches split the partition range over `psplit` workgroups
+    // (planes of Y summed by k_inv) so that the launch still fills the chip
     __shared__ float4 s_win[(SLOTGAIN ? 8 : 4) * MAC_WQ];
     const int bin = blockIdx.x & (MC_NB - 1);
-    const int tile = blockIdx.x >> 8;
+    const int rest = blockIdx.x >> 8;
+    const int tile = rest / psplit, split = rest - tile * psplit;
     const int t0 = tile * 256;
+    p_begin += split * pchunk;
+    p_end = min(p_end, p_begin + pchunk);
+    Y += (size_t)split * MC_NB * tcap;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float4* H0k = H0 + (size_t)bin * pstride_ir;
@@ -484,11 +491,11 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
 // K3: packed inverse transform.  W = Y_L + j Y_R (Hermitian-extended), one
 // 512-point inverse per block, real part = left segment, imaginary = right
 // (replaces the two cufftExecC2C inverse calls, conv.cu:403-408).
-// Y element (bin k, block t) = sum_{c<nsum} Ysrc[k*sk + t*st + c].
+// Y element (bin k, block t) = sum_{c<nsum} Ysrc[k*sk + t*st + c*sc].
 // seg[(seg0 + t) mod sr][ch][512].   grid = ceil(T/8), block = 256.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int T,
-                                             float* __restrict__ seg, int sr, int seg0,
+__global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
+                                             int T, float* __restrict__ seg, int sr, int seg0,
                                              const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
         if (t < T) {
             const float4* src = Ysrc + (int64_t)k * sk + (int64_t)t * st;
             for (int c = 0; c < nsum; c++) {
-                float4 a = src[c];
+                float4 a = src[c * sc];
                 y.x += a.x;
                 y.y += a.y;
                 y.z += a.z;

@@ -494,28 +494,37 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     int64_t sk, stt;
     int nsum, swept = 0, launched = 0;
     const float4* ysrc;
+    int64_t sc = 1;
     if (resident) {
+        // short batches: split the partition range so that the launch has ~2048 workgroups
+        const int tiles = (T + 255) / 256;
+        const int psplit = std::max(1, std::min(8, 8 / tiles));
+        const int tcap = psplit > 1 ? tiles * 256 : e->Tmax;  // plane stride of Y (planes summed by k_inv)
         for (int a = 0; a < st.nact; a++) {
             const ActiveVoice& av = st.act[a];
             int p_begin, p_end;
             partition_range(e, av.p_end, &p_begin, &p_end);
             if (p_end <= p_begin) continue;
-            const dim3 grid(MC_NB * ((T + 255) / 256));
+            const int pchunk = round_up((p_end - p_begin + psplit - 1) / psplit, 16);
+            const dim3 grid(MC_NB * tiles * psplit);
             const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
             if (av.uniform && pstride == 0)
                 hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
-                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, e->Tmax, launched ? 1 : 0);
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
+                                   psplit, pchunk);
             else
                 hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
-                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, e->Tmax, launched ? 1 : 0);
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
+                                   psplit, pchunk);
             launched++;
             swept = std::max(swept, p_end - p_begin);
         }
-        if (!launched) HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * e->Tmax, e->stream));
+        if (!launched) HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * tcap * psplit, e->stream));
         ysrc = e->d_Y;
-        sk = e->Tmax;
+        sk = tcap;
         stt = 1;
-        nsum = 1;
+        nsum = psplit;
+        sc = (int64_t)MC_NB * tcap;
     } else {
         // streaming: one set of chunk partials per sounding voice, all added by k_inv
         int nv = 0;
@@ -546,7 +555,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     }
 
     // K3 (+ K4 for shards)
-    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, stt, nsum, T, e->d_seg,
+    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, stt, nsum, sc, T, e->d_seg,
                        e->sr, seg0, e->d_tw);
     if (lin) hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, lin);
     HIP_TRY(hipGetLastError());
@@ -777,7 +786,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
     e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
-    e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 96;  // measured crossover ~80 blocks (scripts/sweep_T.sh)
+    e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
     e->half = cfg->precision == 1;
@@ -799,7 +808,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
-    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * e->Tmax));
+    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * std::max(e->Tmax, 2048)));  // >= 8 planes of 256 blocks
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
@@ -1129,7 +1138,7 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
             cap = sizeof(float4) * (uint64_t)MC_NB * e->Pstride;
             break;
         case 1: src = (const char*)e->d_fdl; cap = sizeof(float4) * (uint64_t)MC_NB * e->ring; break;
-        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * e->Tmax; break;
+        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * std::max(e->Tmax, 2048); break;
         case 3: src = (const char*)e->d_seg; cap = sizeof(float) * (uint64_t)e->sr * 2 * FFT_N; break;
         case 4: src = (const char*)e->d_wet; cap = sizeof(float) * 2 * (uint64_t)e->wr; break;
         case 5: src = (const char*)e->d_cring; cap = sizeof(double) * 4 * (uint64_t)e->rc; break;
