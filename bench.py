@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], the one the metric is quoted on): stereo
 44.1 kHz, 256-frame blocks, 10 s / 441 000-tap IR (P = 1723 partitions,
 N_ref = 524288), reference routing (2 inputs x 2 outputs = 4 convolution
-paths), fp32.  One "step" = one batch of --blocks consecutive blocks pushed
+paths), fp32.  One "step" = one batch of --blocks (default 8192) consecutive blocks pushed
 through forward FFT -> partition x bin MAC -> inverse FFT -> overlap-add ->
 predelay / Q1-Q2 terms / clamp / dry mix, inputs and outputs resident in HBM.
 
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=2048, help="blocks per step (batch length T)")
+    ap.add_argument("--blocks", type=int, default=8192, help="blocks per step (batch length T; 8192 = 47.6 s of audio)")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
                     help="N > 1: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --force-sharded on one GPU: use the partition shard rank 0 of this many ranks would own")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the partial / collective / finish path even with one rank (rehearsal on one GPU)")
     return ap.parse_args()
@@ -136,20 +138,19 @@ def main():
     ir = make_ir(a.taps, seed=5678)
     P = (min(a.taps, a.fft_size - 1024) + BLOCK - 1) // BLOCK
     # shard bounds: multiples of 16 partitions
-    if world > 1:
-        per = ((P + world - 1) // world + 15) // 16 * 16
-        pb, pe = rank * per, min((rank + 1) * per, (P + 15) // 16 * 16)
-        pb = min(pb, pe)
-        if pe == pb:  # empty shard: keep a valid, empty range
-            pe = pb
+    from cuda_audio_amd.sharded import shard_bounds
+
+    shard_world = world if world > 1 else (a.emulate_world if a.force_sharded and a.emulate_world > 1 else 1)
+    if shard_world > 1:
+        pb, pe = shard_bounds(P, shard_world, rank)
     else:
         pb, pe = 0, 0
     if a.precision == "fp16":
         a.mode = "stream"
     thr = (T + 1) if a.mode == "stream" else 0
     eng = Convolution("bench", a.fft_size, max_batch=T, device=local, part_begin=pb,
-                      part_end=pe if world > 1 else 0, stream_threshold=min(thr, 4096), precision=a.precision)
-    if world > 1 and pe == pb:
+                      part_end=pe if shard_world > 1 else 0, stream_threshold=min(thr, 16385), precision=a.precision)
+    if shard_world > 1 and pe == pb:
         raise SystemExit("empty shard; use fewer ranks")
     # two distinct IRs (seed 5678 + path): in1 -> (L,R) through IR 0, in2 -> (L,R) through IR 1,
     # i.e. four different convolution paths, so the 4-path byte count has no shared spectra

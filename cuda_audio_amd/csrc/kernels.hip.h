@@ -605,32 +605,25 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
     }
 }
 
-#define CORR_NT 256  // one small workgroup: few registers, so it runs beside the MAC waves on the side stream
+// Prefix sums over the batch, spread over many CUs (one CU alone moves only ~15 GB/s):
+//   k_corr_terms: one workgroup per 256 blocks computes the blocks' terms, scans them locally (inclusive) into
+//                 the ring and leaves the chunk total in ctot[chunk];
+//   k_corr_fix  : one workgroup per 256 blocks adds its chunk's base = previous batch's last sums + totals of
+//                 the chunks before it.  Afterwards cring[t] = cumulative {D_L, D_R, Q_L, Q_R} up to block t.
+#define CORR_CHUNK 256
 
-__global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
-                                                  int pstride, int T, VoiceSums vs, double inv_n, int compat,
-                                                  double* __restrict__ cring, int rc, int64_t tabs0) {
-    // cring: [rc][4] = cumulative {D_L, D_R, Q_L, Q_R} up to and including block (index mod rc).
-    // Thread tid owns the consecutive blocks tid*per .. ; pass 1 sums their terms, a 256-wide scan joins
-    // the threads, pass 2 recomputes the terms and writes the running sums (nothing is kept in registers
-    // between the passes: the kernel must stay small enough to co-reside with the partition sweep).
-    __shared__ double s_part[CORR_NT][4];
+__global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
+                                                           int pstride, int T, VoiceSums vs, double inv_n, int compat,
+                                                           double* __restrict__ cring, int rc, int64_t tabs0,
+                                                           double* __restrict__ ctot) {
+    __shared__ double s_part[CORR_CHUNK][4];
     const int tid = threadIdx.x;
-    const int per = (T + CORR_NT - 1) / CORR_NT;
-    double run[4] = {0, 0, 0, 0};
-    if (compat) {
-        for (int j = 0; j < per; j++) {
-            const int t = tid * per + j;
-            if (t < T) {
-                double d[4];
-                corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
-                for (int c = 0; c < 4; c++) run[c] += d[c];
-            }
-        }
-    }
-    for (int c = 0; c < 4; c++) s_part[tid][c] = run[c];
+    const int t = blockIdx.x * CORR_CHUNK + tid;
+    double d[4] = {0, 0, 0, 0};
+    if (t < T && compat) corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
+    for (int c = 0; c < 4; c++) s_part[tid][c] = d[c];
     __syncthreads();
-    for (int off = 1; off < CORR_NT; off <<= 1) {  // inclusive Hillis-Steele scan of the per-thread totals
+    for (int off = 1; off < CORR_CHUNK; off <<= 1) {  // inclusive Hillis-Steele scan
         double v[4] = {0, 0, 0, 0};
         if (tid >= off)
             for (int c = 0; c < 4; c++) v[c] = s_part[tid - off][c];
@@ -638,23 +631,27 @@ __global__ __launch_bounds__(CORR_NT) void k_corr(const float4* __restrict__ sum
         for (int c = 0; c < 4; c++) s_part[tid][c] += v[c];
         __syncthreads();
     }
+    if (t < T) {
+        double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) o[c] = s_part[tid][c];
+    }
+    if (tid == CORR_CHUNK - 1)
+        for (int c = 0; c < 4; c++) ctot[blockIdx.x * 4 + c] = s_part[tid][c];
+}
+
+__global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restrict__ cring, int rc, int64_t tabs0,
+                                                         const double* __restrict__ ctot) {
+    const int t = blockIdx.x * CORR_CHUNK + threadIdx.x;
     double base[4] = {0, 0, 0, 0};
     if (tabs0 > 0) {
         const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) base[c] = p[c];
     }
-    for (int c = 0; c < 4; c++) base[c] += s_part[tid][c] - run[c];  // exclusive prefix of this thread
-    for (int j = 0; j < per; j++) {
-        const int t = tid * per + j;
-        if (t < T) {
-            if (compat) {
-                double d[4];
-                corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
-                for (int c = 0; c < 4; c++) base[c] += d[c];
-            }
-            double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
-            for (int c = 0; c < 4; c++) o[c] = base[c];
-        }
+    for (int k = 0; k < (int)blockIdx.x; k++)  // wave-uniform addresses: broadcast loads
+        for (int c = 0; c < 4; c++) base[c] += ctot[k * 4 + c];
+    if (t < T) {
+        double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) o[c] += base[c];
     }
 }
 

@@ -82,6 +82,7 @@ struct mc_engine {
     float4 *d_fdl = nullptr, *d_slotgain = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
     float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
+    double* d_ctot = nullptr;   // [ceil(Tmax/256)][4] chunk totals of the Q1/Q2 prefix sums
     float* d_xhist = nullptr;   // [2][xr] input history (Q8 pass)
     float4* d_gring = nullptr;  // [MC_MAXV][rc] wet gains of past blocks (Q8 pass)
     int xr = 0;
@@ -578,8 +579,11 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
         const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
         // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
-        hipLaunchKernelGGL(k_corr, dim3(1), dim3(CORR_NT), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
-                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0);
+        const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
+        hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
+                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot);
+        hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
+                           e->d_ctot);
         hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
                            e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
                            (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
@@ -762,7 +766,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (cfg->struct_size != sizeof(mc_config)) return fail(MC_ERR_ARG, "mc_config size mismatch (%u vs %zu)", cfg->struct_size, sizeof(mc_config));
     if (cfg->n_ref < 4096 || (cfg->n_ref & (cfg->n_ref - 1))) return fail(MC_ERR_ARG, "n_ref must be a power of two >= 4096");
     if (cfg->n_ref > (1ull << 26)) return fail(MC_ERR_ARG, "n_ref too large");
-    if (cfg->max_batch < 1 || cfg->max_batch > 4096) return fail(MC_ERR_ARG, "max_batch must be in [1, 4096]");
+    if (cfg->max_batch < 1 || cfg->max_batch > 16384) return fail(MC_ERR_ARG, "max_batch must be in [1, 16384]");
     if ((cfg->part_begin % 16) || (cfg->part_end % 16)) return fail(MC_ERR_ARG, "partition shard bounds must be multiples of 16");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -814,6 +818,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
+    ENG_TRY(hipMalloc(&e->d_ctot, sizeof(double) * 4 * (size_t)((e->Tmax + 255) / 256 + 1)));
     e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B + MC_MAX_PREDELAY + 1024);
     ENG_TRY(hipMalloc(&e->d_xhist, sizeof(float) * 2 * (size_t)e->xr));
     ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
@@ -866,6 +871,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_seg);
     (void)hipFree(e->d_wet);
     (void)hipFree(e->d_cring);
+    (void)hipFree(e->d_ctot);
     (void)hipFree(e->d_xhist);
     (void)hipFree(e->d_gring);
     (void)hipFree(e->d_ptab);

@@ -8,7 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${TAG}_${MODE}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 10 --warmup 2 --mode $MODE --no-cpu-baseline --no-latency"
+EXTRA=""; [ "$MODE" = "stream" ] && EXTRA="--blocks 2048"
+ARGS="$REPO/bench.py --steps 10 --warmup 2 --mode $MODE --no-cpu-baseline --no-latency $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || exit 1
