@@ -49,23 +49,22 @@ int main(int argc, char** argv) {
                 c->cc[i].device = dev;
                 dev->handler = c;
             }
-            c->cc[i].message = settings.u8("conv[%d].cc.message", idx);
-            c->cc[i].select = settings.u8("conv[%d].cc.select", idx);
-            c->cc[i].predelay = settings.u8("conv[%d].cc.predelay", idx);
-            c->cc[i].dry = settings.u8("conv[%d].cc.dry", idx);
-            c->cc[i].wet = settings.u8("conv[%d].cc.wet", idx);
-            c->cc[i].speed = settings.u8("conv[%d].cc.speed", idx);
-            c->cc[i].panDry = settings.u8("conv[%d].cc.panDry", idx);
-            c->cc[i].panWet = settings.u8("conv[%d].cc.panWet", idx);
-            c->cc[i].level = settings.u8("conv[%d].cc.level", idx);
-            c->cc[i].value.select = settings.u32("conv[%d].value.select", idx);
-            c->cc[i].value.predelay = settings.u32("conv[%d].value.predelay", idx);
-            c->cc[i].value.dry = settings.f32("conv[%d].value.dry", idx);
-            c->cc[i].value.wet = settings.f32("conv[%d].value.wet", idx);
-            c->cc[i].value.speed = settings.u32("conv[%d].value.speed", idx);
-            c->cc[i].value.panDry = settings.f32("conv[%d].value.panDry", idx);
-            c->cc[i].value.panWet = settings.f32("conv[%d].value.panWet", idx);
-            c->cc[i].value.level = settings.f32("conv[%d].value.level", idx);
+            // MIDI controller numbers and initial values, table-driven: "conv[<idx>].cc.<name>" / ".value.<name>"
+            Convolution::CC& half = c->cc[i];
+            struct { const char* name; uint8_t* slot; } controllers[] = {
+                {"message", &half.message}, {"select", &half.select},   {"predelay", &half.predelay},
+                {"dry", &half.dry},         {"wet", &half.wet},         {"speed", &half.speed},
+                {"panDry", &half.panDry},   {"panWet", &half.panWet},   {"level", &half.level}};
+            for (auto& k : controllers) *k.slot = settings.u8("conv[%d].cc.%s", idx, k.name);
+            struct { const char* name; size_t* slot; } counts[] = {
+                {"select", &half.value.select}, {"predelay", &half.value.predelay}, {"speed", &half.value.speed}};
+            for (auto& k : counts) *k.slot = settings.u32("conv[%d].value.%s", idx, k.name);
+            struct { const char* name; float* slot; } gains[] = {{"dry", &half.value.dry},
+                                                                  {"wet", &half.value.wet},
+                                                                  {"panDry", &half.value.panDry},
+                                                                  {"panWet", &half.value.panWet},
+                                                                  {"level", &half.value.level}};
+            for (auto& k : gains) *k.slot = settings.f32("conv[%d].value.%s", idx, k.name);
 
             std::ifstream index(settings.str("conv[%d].index", idx));
             std::string path;
