@@ -691,3 +691,41 @@ def test_ir_cycling_reuses_voice_slots(oracle_mod, gpu_lib):
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e}"
     c.close()
+
+
+def test_full_size_resident_vs_streaming_with_events(gpu_lib):
+    """BASELINE config-3 size (two 441 000-tap IRs, P = 1723): the resident kernels (uniform and gain-per-slot)
+    and the streaming kernel are independent implementations of the same sum; on a 2600-block stream with pan /
+    level / wet changes and a live IR switch (two voices sounding for a whole IR length) they must agree."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb = 2600
+    x = make_input(nb * 256)
+    irs = [make_ir(441000, seed=5678), make_ir(441000, seed=5680), make_ir(300000, seed=5690)]
+    events = {300: (0, dict(panWet=0.5)), 700: (1, dict(level=0.8, wet=0.4)), 1200: (0, dict(select=2, vsteps=40)),
+              1900: (1, dict(panWet=-0.5)), 2300: (0, dict(dry=0.2))}
+
+    def run(max_batch, thr):
+        c = _conv(fftSize=524288, max_batch=max_batch, stream_threshold=thr)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        c.cc[1].value.select = 1
+        out = np.zeros((2, nb * 256), np.float32)
+        b = 0
+        while b < nb:
+            if b in events:
+                half, kw = events[b]
+                c.cc[half].value.update(**kw)
+            nxt = min([e for e in events if e > b] + [nb])
+            n = min(max_batch, nxt - b)
+            s = slice(b * 256, (b + n) * 256)
+            out[:, s] = c.process(x[0, s], x[1, s])
+            b += n
+        c.close()
+        return out
+
+    res = run(512, 1)       # resident kernels only
+    stm = run(100, 101)     # streaming kernel only
+    assert np.abs(res).max() > 0.05
+    err = rms(res - stm)
+    assert err < 2e-6, f"resident vs streaming rms {err:.3e} (signal {rms(res):.3e})"
