@@ -143,7 +143,6 @@ struct mc_engine {
     // avgRuntime (conv.cu:454-462): first 10 calls discarded
     double runtime_ms = 0;
     int nruns = -10;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // kernel timing
     bool ktiming = false;
@@ -833,8 +832,6 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
-    ENG_TRY(hipEventCreate(&e->ev0));
-    ENG_TRY(hipEventCreate(&e->ev1));
     {
         std::vector<float2> tw;
         host_twiddles(tw);
@@ -885,8 +882,6 @@ void mc_destroy(mc_engine* e) {
         }
     }
     if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->kev_created)
         for (int i = 0; i < kEvPool; i++) {
             (void)hipEventDestroy(e->kev[i][0]);
