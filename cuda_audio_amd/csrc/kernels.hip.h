@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                                                int rc, VoiceSums vs, double inv_n, int compat, int64_t tabs0,
                                                int64_t predelay, int64_t n_ref, float* __restrict__ outL,
                                                float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td,
-                                               uint2* __restrict__ fdl16) {
+                                               uint2* __restrict__ fdl16, unsigned* __restrict__ done_flag, unsigned seq) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
     __shared__ float4 s_x[MC_NB];  // raw spectra of the new block {X1, X2}
@@ -1021,4 +1021,9 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
         outR[m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
     }
+    // publish completion to the host (mapped pinned memory): every thread's output stores are made visible
+    // system-wide before the sequence number is
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -91,6 +91,10 @@ struct mc_engine {
     float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // in1, in2, outL, outR staging for host-pointer calls
     float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Tmax * 256
     float* hd_io = nullptr;                                 // device-side address of h_io (mapped, zero-copy)
+    unsigned* h_flag = nullptr;                             // completion word of the single-period path (mapped)
+    unsigned* hd_flag = nullptr;
+    unsigned flag_seq = 0;
+    bool spin_wait = true;
     BlockParams* h_ptab[kStageBufs] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ptab_ev[kStageBufs];
     bool ptab_ev_used[kStageBufs] = {false, false, false, false};
@@ -682,9 +686,9 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                        e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, seg0, e->d_wet, e->wr,
                        e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,
                        (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16);
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
+    if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
     e->t_front += 1;
     e->t_abs = e->t_front;
@@ -703,7 +707,23 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             e->spec_vir[1][a] = st.ctx.vir[1][sweep[a].v];
         }
     }
-    HIP_TRY(hipEventSynchronize(e->ev_tail));  // the output of THIS block is on the host; the speculative sweep runs on
+    // the output of THIS block is on the host once k_tail1 has published its sequence number; the speculative
+    // sweep keeps running.  Spin on the mapped word (a JACK callback blocks here anyway; the reference blocks in
+    // cudaEventSynchronize, conv.cu:455); fall back to a stream sync if it does not arrive in time.
+    if (e->spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) return fail(MC_ERR_HIP, "period did not complete");
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    } else {
+        HIP_TRY(hipEventSynchronize(e->ev_tail));
+    }
     std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
     std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * MC_B);
     return MC_OK;
@@ -826,6 +846,10 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
     ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Tmax * MC_B, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
+    ENG_TRY(hipHostMalloc(&e->h_flag, 64, hipHostMallocMapped));
+    ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
+    *e->h_flag = 0;
+    if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
     for (int i = 0; i < kStageBufs; i++) {
         ENG_TRY(hipHostMalloc(&e->h_ptab[i], sizeof(BlockParams) * (size_t)e->Tmax, hipHostMallocDefault));
         ENG_TRY(hipEventCreateWithFlags(&e->ptab_ev[i], hipEventDisableTiming));
@@ -875,6 +899,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_tw);
     for (int i = 0; i < 4; i++) (void)hipFree(e->d_io[i]);
     if (e->h_io) (void)hipHostFree(e->h_io);
+    if (e->h_flag) (void)hipHostFree(e->h_flag);
     for (int i = 0; i < kStageBufs; i++) {
         if (e->h_ptab[i]) {
             (void)hipHostFree(e->h_ptab[i]);
