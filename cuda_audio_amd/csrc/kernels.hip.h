@@ -1021,9 +1021,11 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
         outR[m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
     }
-    // publish completion to the host (mapped pinned memory): every thread's output stores are made visible
-    // system-wide before the sequence number is
-    __threadfence_system();
+    // publish completion to the host (mapped pinned memory): all waves drain their stores at the barrier
+    // (__syncthreads waits vmcnt(0)), then ONE lane issues the system-scope release and the sequence number
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
