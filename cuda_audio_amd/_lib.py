@@ -17,7 +17,7 @@ MC_MAX_PREDELAY = 8192
 # every symbol include/mcconv.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_default_config", "mc_default_params", "mc_create", "mc_destroy",
-    "mc_reset", "mc_load_ir", "mc_num_irs", "mc_ir_info", "mc_set_params", "mc_get_params", "mc_handle_cc",
+    "mc_reset", "mc_set_period", "mc_load_ir", "mc_num_irs", "mc_ir_info", "mc_set_params", "mc_get_params", "mc_handle_cc",
     "mc_process", "mc_process_batch", "mc_process_batch_device", "mc_partial_batch_device",
     "mc_finish_batch_device", "mc_sync", "mc_set_stream", "mc_get_stream", "mc_avg_runtime_ms",
     "mc_enable_kernel_timing", "mc_get_kernel_stats", "mc_algorithmic_bytes_per_block", "mc_blocks_processed",
@@ -37,7 +37,8 @@ class McConfig(C.Structure):
         ("part_end", C.c_uint32),
         ("stream_threshold", C.c_uint32),
         ("precision", C.c_uint32),
-        ("reserved", C.c_uint32 * 4),
+        ("period", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -102,6 +103,7 @@ def load():
     L.mc_destroy.argtypes = [vp]
     L.mc_destroy.restype = None
     L.mc_reset.argtypes = [vp]
+    L.mc_set_period.argtypes = [vp, C.c_uint32]
     L.mc_load_ir.argtypes = [vp, u64, fp, u64, u64]
     L.mc_num_irs.argtypes = [vp]
     L.mc_ir_info.argtypes = [vp, u64, C.POINTER(C.c_double)]

@@ -681,15 +681,16 @@ struct TailDrop {
 __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
                                           const BlockParams* __restrict__ ptab, int pstride, int rc,
                                           const float* __restrict__ cur1, const float* __restrict__ cur2, float& dl,
-                                          float& dr) {
+                                          float& dr, int m = 1) {
     dl = dr = 0.f;
     const int64_t v = tau - n_ref;
     if (v < 0) return;
-    const int64_t hi_tb = v >> 8;
+    // blocks of every call (m blocks each) that started at or before tau - n_ref
+    const int64_t hi_tb = ((v >> 8) / m + 1) * m - 1;
     const int64_t lo = tau - pd - 254 - td.lmax;
     const int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
     for (int64_t tb = lo_tb; tb <= hi_tb; tb++) {
-        const int64_t s = tau - pd - (tb << 8);  // position inside block tb's contribution, >= n_ref - pd
+        const int64_t s = tau - pd - (tb << 8);  // position inside block tb's own contribution
         const int64_t rel = tb - (tau0 >> 8);
         const int64_t base = tb << 8;
 #pragma unroll
@@ -752,7 +753,8 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
-                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td) {
+                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td, int pm) {
+    // pm = blocks per reference call (JACK period / 256): Q1/Q2/Q8 windows are measured from the call start
     const int t = blockIdx.x, m = threadIdx.x;
     const int64_t i = (int64_t)t * MC_B + m;
     const int64_t tau0 = tabs0 * MC_B;
@@ -774,10 +776,11 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     }
     double cl = 0.0, cr = 0.0;
     if (compat && u >= 0) {
-        // input blocks t' with predelay <= tau - 256 t' < n_ref (shift by predelay, cut at n_ref: Q8)
-        const int64_t thi = u >> 8;
+        // calls q (pm blocks each) with predelay <= tau - q*period < n_ref (shift by predelay, cut at n_ref: Q8);
+        // prefix sums are per block, so a call ends at block (q + 1) pm - 1
+        const int64_t thi = ((u >> 8) / pm + 1) * pm - 1;
         const int64_t v = tau - n_ref;
-        const int64_t tlo = v >= 0 ? (v >> 8) : -1;
+        const int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
         const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
         double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
         if (tlo >= 0) {
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     write_history(td, tau, tabs0 + t, m, x1, x2, bp, rc);
     if (td.on) {
         float dl, dr;
-        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr);
+        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm);
         wl -= dl;
         wr_ -= dr;
     }

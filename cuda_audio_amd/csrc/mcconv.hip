@@ -73,6 +73,7 @@ struct mc_engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
     int stream_threshold = 0;
+    int pm = 1;  // blocks per reference call (JACK period / 256): 1, 2 or 4
     int stream_nt = 256;
     IrEntry irs[kMaxIrs];
     int nirs = 0;
@@ -245,7 +246,9 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
         const uint64_t blk = e->t_front + (uint64_t)t;
         BlockParams& bp = tab[t];
         std::memset(&bp, 0, sizeof(bp));
-        for (int i = 0; i < 2; i++) {
+        // the reference advances its live spectra once per onProcess call: with periods of 512 / 1024 frames the
+        // 2 / 4 internal blocks of a call share the call's coefficients
+        for (int i = 0; i < 2 && (blk % (uint64_t)e->pm) == 0; i++) {
             const double wet = (double)cc[i].wet;
             const double div = (double)(cc[i].vsteps + 5);
             const int sv = voice_slot_for(e, i, (int)cc[i].select, blk);
@@ -346,7 +349,7 @@ int stage_params(mc_engine* e, int T, Staged* st) {
         // vsteps counts down on the engine's copy too (conv.cu:345,353)
         std::lock_guard<std::mutex> lk(e->pmu);
         for (int i = 0; i < 2; i++) {
-            uint64_t used = std::min<uint64_t>(e->cc[i].vsteps, (uint64_t)T);
+            uint64_t used = std::min<uint64_t>(e->cc[i].vsteps, (uint64_t)(T / e->pm));
             e->cc[i].vsteps -= used;
         }
     }
@@ -466,6 +469,7 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
 int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin) {
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
     if (e->pipe_count >= kPipe) return fail(MC_ERR_STATE, "%d batches already await mc_finish_batch_device", kPipe);
+    if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
     Staged st;
     {
         int rc = stage_params(e, T, &st);
@@ -590,7 +594,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
                            e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
                            (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
-                           make_taildrop(e, ctx.vir, ctx.predelay));
+                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm);
         HIP_TRY(hipGetLastError());
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
@@ -812,6 +816,18 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
+    {
+        const uint32_t period = cfg->period ? cfg->period : MC_BLOCK;
+        if (period != 256 && period != 512 && period != 1024) {
+            delete e;
+            return fail(MC_ERR_ARG, "period must be 256, 512 or 1024 frames");
+        }
+        e->pm = (int)(period / MC_BLOCK);
+        if (e->Tmax % e->pm) {
+            delete e;
+            return fail(MC_ERR_ARG, "max_batch must be a multiple of period / 256");
+        }
+    }
     e->half = cfg->precision == 1;
     if (e->half) e->stream_threshold = e->Tmax + 1;  // the fp16 MAC is the streaming sweep
     e->Tstream = std::min(e->Tmax, std::max(1, e->stream_threshold - 1));
@@ -920,6 +936,17 @@ int mc_reset(mc_engine* e) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
     return zero_state(e);
+}
+
+int mc_set_period(mc_engine* e, uint32_t nframes) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    if (nframes != 256 && nframes != 512 && nframes != 1024) return fail(MC_ERR_ARG, "period must be 256, 512 or 1024 frames");
+    const int pm = (int)(nframes / MC_BLOCK);
+    if (e->Tmax % pm) return fail(MC_ERR_ARG, "max_batch %d is not a multiple of %d blocks", e->Tmax, pm);
+    if (pm == e->pm) return MC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    e->pm = pm;
+    return zero_state(e);  // the per-call semantics change: start from the cold state
 }
 
 int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uint64_t nframes) {
@@ -1034,12 +1061,14 @@ int mc_handle_cc(mc_engine* e, int half, const uint8_t ccmap[8], uint8_t m2, int
 
 int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, uint64_t nframes) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
-    if (nframes != MC_BLOCK) return fail(MC_ERR_ARG, "nframes must be %d (got %llu)", MC_BLOCK, (unsigned long long)nframes);
+    if (nframes != (uint64_t)MC_BLOCK * e->pm)
+        return fail(MC_ERR_ARG, "nframes must be %d (got %llu)", MC_BLOCK * e->pm, (unsigned long long)nframes);
     HIP_TRY(hipSetDevice(e->device));
     // the reference brackets its GPU work with events (conv.cu:299-302, 454-462); the call below
     // returns only when the output is on the host, so a host clock around it measures a superset
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = process_one(e, in1, in2, outL, outR);
+    // 256-frame periods take the fused single-block path; 512 / 1024 run as one small batch
+    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR) : process_host(e, in1, in2, outL, outR, e->pm);
     if (rc) return rc;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (++e->nruns > 0) e->runtime_ms += ms;  // first 10 calls discarded, conv.h:80

@@ -80,7 +80,7 @@ class CC:
 
 class Convolution:
     def __init__(self, name="Conv", fftSize=CONV_DEFAULT_FFTSIZE, *, max_batch=256, device=-1, compat=True,
-                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32"):
+                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32", period=256):
         self.name = name
         self._L = _lib.load()
         cfg = McConfig()
@@ -93,6 +93,7 @@ class Convolution:
         cfg.max_partitions = max_partitions
         cfg.stream_threshold = stream_threshold
         cfg.precision = {"fp32": 0, "fp16": 1}[precision]
+        cfg.period = period
         h = C.c_void_p()
         check(self._L.mc_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -114,6 +115,10 @@ class Convolution:
 
     def reset(self):
         check(self._L.mc_reset(self._h))
+
+    def set_period(self, nframes):
+        """JACK period the host calls onProcess with: 256, 512 or 1024 frames (resets the signal state)."""
+        check(self._L.mc_set_period(self._h, nframes))
 
     # -- reference surface ----------------------------------------------------
     def prepare(self, idx, wav, nframes=1024):

@@ -76,6 +76,10 @@ void Convolution::onProcess(size_t nframes) {
     auto L = playback[0] ? (float*)jack_port_get_buffer(playback[0], nframes) : nullptr;
     auto R = playback[1] ? (float*)jack_port_get_buffer(playback[1], nframes) : nullptr;
     if (!in1 || !in2 || !L || !R) return;  // conv.cu:297
+    if (nframes != _period) {  // jackd decides the period (256 on the README's target, 512 / 1024 in the run scripts)
+        check(mc_set_period(_engine, (uint32_t)nframes), "mc_set_period");
+        _period = nframes;
+    }
     pushParams();
     check(mc_process(_engine, in1, in2, L, R, nframes), "mc_process");
     pullVsteps();

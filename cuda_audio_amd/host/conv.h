@@ -69,6 +69,7 @@ private:
     mc_engine* _engine = nullptr;
     size_t _fftSize;
     size_t _nirs = 0;
+    size_t _period = 256;
     void pushParams();
     void pullVsteps();
 };

@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define MC_ABI_VERSION 1
-#define MC_BLOCK 256          /* frames per block (JACK period the engine is built for) */
+#define MC_BLOCK 256          /* frames per internal block (and the default JACK period) */
 #define MC_MAX_PREDELAY 8192  /* conv.h:26-28 */
 #define MC_MAX_SPEED 1024     /* conv.h:22-24 */
 
@@ -68,7 +68,11 @@ typedef struct {
                                (0 = default) */
     uint32_t precision;     /* 0 = fp32 spectra; 1 = fp16 storage of IR spectra and delay line for the
                                partition sweep (fp32 products and sums; streaming kernel only) */
-    uint32_t reserved[4];
+    uint32_t period;        /* JACK period the host will call mc_process with: 0/256, 512 or 1024 frames.  The
+                               reference's per-call semantics (cross-fade step, DC/Nyquist and tail-drop windows)
+                               follow this size; internally a period is 1, 2 or 4 blocks of 256.  Batch calls
+                               take multiples of period/256 blocks. */
+    uint32_t reserved[3];
 } mc_config;
 
 /* mirrors Convolution::CC::value (conv.h:38-49); same defaults via mc_default_params */
@@ -97,6 +101,8 @@ void mc_default_params(mc_cc_value *v);
 int mc_create(const mc_config *cfg, mc_engine **out);
 void mc_destroy(mc_engine *e);
 int mc_reset(mc_engine *e); /* zero all signal state (delay line, tails, cross-fade) */
+/* change the JACK period (256, 512 or 1024 frames; see mc_config.period); resets the signal state */
+int mc_set_period(mc_engine *e, uint32_t nframes);
 
 /* lr: interleaved L,R float frames as WavFile holds them (already scaled, wav.cu Q5);
  * nframes: the reference's third prepare() argument (1024). Host pointer. */

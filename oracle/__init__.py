@@ -164,17 +164,17 @@ class _Engine:
             for k, val in kw.items():
                 setattr(v, k, val)
 
-    def process(self, in1, in2):
-        """Run consecutive 256-frame blocks; returns float64 [2, n]."""
+    def process(self, in1, in2, block=BLOCK):
+        """Run consecutive `block`-frame periods (256 unless stated); returns float64 [2, n]."""
         in1, in2 = _f32(in1), _f32(in2)
         n = len(in1)
-        assert n % BLOCK == 0 and len(in2) == n
+        assert n % block == 0 and len(in2) == n
         out = np.zeros((2, n), dtype=np.float64)
         f = getattr(lib(), self._process)
-        for b in range(n // BLOCK):
-            s = slice(b * BLOCK, (b + 1) * BLOCK)
+        for b in range(n // block):
+            s = slice(b * block, (b + 1) * block)
             a, bb = in1[s], in2[s]
-            f(self._h, _fp(a), _fp(bb), _dp(out[0, s]), _dp(out[1, s]), BLOCK)
+            f(self._h, _fp(a), _fp(bb), _dp(out[0, s]), _dp(out[1, s]), block)
         return out
 
 

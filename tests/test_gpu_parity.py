@@ -729,3 +729,45 @@ def test_full_size_resident_vs_streaming_with_events(gpu_lib):
     assert np.abs(res).max() > 0.05
     err = rms(res - stm)
     assert err < 2e-6, f"resident vs streaming rms {err:.3e} (signal {rms(res):.3e})"
+
+
+@pytest.mark.parametrize("period", [512, 1024])
+@pytest.mark.parametrize("pd,taps", [(300, (2500, 2800)), (1024, (3072, 3072))], ids=["pd300", "pd1024_taildrop"])
+def test_longer_jack_periods(oracle_mod, gpu_lib, period, pd, taps):
+    """The reference's run scripts start jackd with 512- (x86) and 1024-frame (Jetson) periods.  Its per-call
+    semantics then change — one cross-fade step per call, DC/Nyquist (Q1/Q2) and tail-drop (Q8) windows
+    measured from the call start — while the convolution itself is the same.  Engine: 2 / 4 internal blocks per
+    period sharing the call's gains and window origin; onProcess and batch calls; cold start included."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, ncalls = 4096, 80
+    n = ncalls * period
+    x = make_input(n)
+    irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05)]
+    p0 = dict(BASE, predelay=pd, wet=0.7, panWet=0.25, vsteps=9)
+    p1 = dict(BASE, select=1, level=0.8)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    want = ref.process(x[0], x[1], block=period)
+    # one period per call (what JACK does)
+    c = _conv(fftSize=n_ref, max_batch=16, period=period)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    got = np.concatenate([np.stack(c.onProcess(x[0, k * period:(k + 1) * period], x[1, k * period:(k + 1) * period]))
+                          for k in range(ncalls)], axis=1)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"onProcess: rms {err:.3e}"
+    # batches of whole periods through the resident kernel
+    c.set_period(256)
+    c.set_period(period)  # resets to the cold state
+    apply_params(c, p0, p1, False)
+    got2 = c.process(x[0], x[1])
+    assert rms(got2 - want) <= RMS_TOL
+    from cuda_audio_amd._lib import McError
+
+    with pytest.raises(McError):
+        c.onProcess(x[0, :256], x[1, :256])  # wrong period length
+    c.close()
