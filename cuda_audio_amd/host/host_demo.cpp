@@ -3,9 +3,9 @@
 // (processCallback -> onProcess), with IRs loaded from WAV files, optional
 // MIDI controller messages, and raw float32 input/output files.
 //
-//   mcconv_host_demo <fftSize> <in.f32> <out.f32> <nblocks> <ir0.wav> [<ir1.wav>]
-//                    [--set half key value]... [--cc half controller value @block]...
-// in.f32 holds [2][nblocks*256] floats (channel-major); out.f32 likewise.
+//   mcconv_host_demo <fftSize> <in.f32> <out.f32> <nperiods> <ir0.wav> [<ir1.wav>]
+//                    [--period 256|512|1024] [--set half key value]... [--cc half controller value @period]...
+// in.f32 holds [2][nperiods*period] floats (channel-major); out.f32 likewise.
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
@@ -51,8 +51,13 @@ int main(int argc, char** argv) {
     Log::quiet(true);
     const size_t fftSize = strtoull(argv[1], nullptr, 10);
     const uint64_t nblocks = strtoull(argv[4], nullptr, 10);
+    // --period N anywhere on the command line: frames per JACK period (256 unless given)
+    unsigned period = 256;
+    for (int i = 5; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--period")) period = (unsigned)atoi(argv[i + 1]);
+    fakejack_configure(44100, period);
     Io io;
-    io.n = nblocks * 256;
+    io.n = nblocks * period;
     io.in.resize(2 * io.n);
     io.out.assign(2 * io.n, 0.f);
     FILE* f = fopen(argv[2], "rb");
@@ -99,6 +104,8 @@ int main(int argc, char** argv) {
             else if (key == "level") val.level = (float)v;
             else { fprintf(stderr, "unknown key %s\n", key.c_str()); return 2; }
             a += 3;
+        } else if (!strcmp(argv[a], "--period") && a + 1 < argc) {
+            a += 1;
         } else if (!strcmp(argv[a], "--cc") && a + 4 < argc) {
             CcEvent e{atoi(argv[a + 1]), atoi(argv[a + 2]), atoi(argv[a + 3]), strtoull(argv[a + 4] + 1, nullptr, 10)};
             io.events.push_back(e);

@@ -126,6 +126,30 @@ def test_convolution_class_through_fake_jack(host_built, oracle_mod, tmp_path):
 
 
 @pytest.mark.gpu
+def test_convolution_class_with_512_frame_period(host_built, oracle_mod, tmp_path):
+    """jackd -p512 (run_x64_86.sh): the C++ Convolution adopts the period jackd calls it with."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    ncalls, n_ref, period = 40, 8192, 512
+    x = make_input(ncalls * period)
+    ir = make_ir(3000, seed=11, norm=0.05)
+    w = str(tmp_path / "ir.wav")
+    _write_wav(w, ir, 24)
+    subprocess.check_call([TOOL, "wavdump", w, str(tmp_path / "d.f32")], stdout=subprocess.DEVNULL)
+    dec = np.fromfile(str(tmp_path / "d.f32"), np.float32).reshape(-1, 2)
+    x.tofile(str(tmp_path / "in.f32"))
+    res = subprocess.run([DEMO, str(n_ref), str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(ncalls), w,
+                          "--period", str(period), "--set", "0", "predelay", "1024"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr + res.stdout
+    got = np.fromfile(str(tmp_path / "out.f32"), np.float32).reshape(2, -1)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    ref.prepare(0, dec)
+    ref.set(0, predelay=1024)
+    want = ref.process(x[0], x[1], block=period)
+    assert rms(got - want) <= RMS_TOL
+
+
+@pytest.mark.gpu
 def test_main_flow_with_settings_file(host_built, tmp_path):
     """mcconv_host = the reference's main() order (main.cu:18-116): selectGpu, settings.txt, one Convolution per
     channel pair, MIDI mapping + initial values, IR bank from an index file, start, connect, run, avg runtime.
