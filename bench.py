@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-sharded on one GPU: use the partition shard rank 0 of this many ranks would own")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1 collective backend. gloo is a rehearsal of the launch path on a box with fewer GPUs than "
+                         "ranks (ranks share cards, the sum goes through host memory): never a headline number")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the partial / collective / finish path even with one rank (rehearsal on one GPU)")
     return ap.parse_args()
@@ -120,6 +123,9 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if a.backend == "gloo":
+        local %= max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a card
+        a.collective = "allreduce"                  # gloo has no reduce on device tensors
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sharded = world > 1 or a.force_sharded
@@ -131,6 +137,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif a.backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -347,7 +355,7 @@ def main():
                 "paths": 4,
                 "mode": a.mode,
                 "parallelism": "single GPU" if not sharded else
-                f"IR partitions sharded over {world} GPU(s) + RCCL {a.collective} of partial wet blocks"
+                f"IR partitions sharded over {world} GPU(s) + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} {a.collective} of partial wet blocks"
                 f"{'' if a.no_overlap else ', overlapped with the next batch'}",
             },
             "roofline": roofline,
