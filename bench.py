@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
                     help="N > 1: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
+    ap.add_argument("--no-check", action="store_true",
+                    help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-sharded on one GPU: use the partition shard rank 0 of this many ranks would own")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -173,9 +175,16 @@ def main():
     d_in = torch.from_numpy(xs).to(dev)
     d_out = torch.zeros(2, T * BLOCK, device=dev)
     d_parts = [torch.zeros(2 * T * BLOCK, device=dev) for _ in range(2)] if sharded else None
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one compute stream for the engine, the torch ops and (as the stream the collectives order themselves
+    # against) RCCL: partial -> reduce -> finish are then ordered by the streams, not by host synchronisation
+    torch.cuda.synchronize()
+    comp = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(comp)
+    eng.use_torch_stream(comp)
     root_only = a.collective == "reduce"
     pending = []
+
+    kept = None  # check mode: rank 0 keeps a copy of every finished batch
 
     def retire():
         # second half of the oldest batch in flight: wait for its collective, then predelay / clamp / dry on the sum
@@ -183,6 +192,8 @@ def main():
         work.wait()  # makes the compute stream wait for the collective; the host does not block
         if rank == 0 or not root_only:
             eng.finish_device(i1, i2, part.data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+            if kept is not None and rank == 0:
+                kept.append(d_out.clone())
         else:
             eng.finish_device(None, None, None, None, None, T)
 
@@ -295,6 +306,40 @@ def main():
                     "kernel's average duration in profiles/r1_jack_kernel_stats.csv (same path, same IRs)",
         }
 
+    # Untimed: the sharded pipeline exactly as timed above (two batches in flight, collective on RCCL's stream)
+    # against an unsharded engine fed the same batches from the same cold state, on rank 0.
+    sharded_check = None
+    if sharded and not a.no_check:
+        eng.reset()
+        kept = []
+        nchk = 3
+        for k in range(nchk):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        if rank == 0:
+            full = Convolution("check", a.fft_size, max_batch=T, device=local, stream_threshold=min(thr, 16385),
+                               precision=a.precision)
+            full.prepare(0, ir)
+            full.prepare(1, ir_b)
+            for h in (0, 1):
+                full.cc[h].value.update(select=h, predelay=0, dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
+            full.use_torch_stream(comp)
+            ref_out = torch.zeros_like(d_out)
+            num = den = 0.0
+            for k in range(nchk):
+                o = (k % n_distinct) * T * BLOCK
+                full.process_device(d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr(), ref_out[0].data_ptr(), ref_out[1].data_ptr(), T)
+                torch.cuda.synchronize()
+                num += float(((kept[k] - ref_out).double() ** 2).sum())
+                den += float((ref_out.double() ** 2).sum())
+            n_el = nchk * ref_out.numel()
+            sharded_check = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
+            full.close()
+        kept = None
+        if world > 1:
+            dist.barrier()
+
     cpu = None
     if rank == 0 and not sharded and not a.no_cpu_baseline:
         cpu = cpu_baseline(ir, ir_b, xs, a.cpu_seconds)
@@ -362,6 +407,8 @@ def main():
             "cpu_baseline": cpu,
             "latency_mode": latency,
         }
+        if sharded_check is not None:
+            line["sharded_check"] = sharded_check
         print(json.dumps(line))
     eng.close()
     if sharded:

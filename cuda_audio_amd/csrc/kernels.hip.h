@@ -560,26 +560,71 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
     }
 }
 
-// Wet signal of sample (t, m) of the current batch: either the overlap-add of
-// this block's first half with the previous block's second half straight from
-// the segment ring (single engine), or the caller's summed linear buffer (shards).
-__device__ __forceinline__ float2 batch_wet(const float* __restrict__ seg, int sr, int seg0, const float* __restrict__ lin,
-                                            int T, int t, int m) {
-    if (lin) return make_float2(lin[(size_t)t * MC_B + m], lin[(size_t)T * MC_B + (size_t)t * MC_B + m]);
+// Wet sample (t, m) of the current batch: the overlap-add of this block's first
+// half with the previous block's second half, straight from the segment ring.
+__device__ __forceinline__ float2 batch_wet(const float* __restrict__ seg, int sr, int seg0, int t, int m) {
     const float* cur = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
     const float* prv = seg + (size_t)((seg0 + t + sr - 1) & (sr - 1)) * 2 * FFT_N;
     return make_float2(cur[m] + prv[MC_B + m], cur[FFT_N + m] + prv[FFT_N + MC_B + m]);
 }
 
 // ---------------------------------------------------------------------------
-// K4 (sharded operation only): overlap-add of this shard's segments into the
-// caller's linear partial buffer [2][T*256] that goes into the cross-GPU sum.
-// (A single engine needs no such pass: k_post overlap-adds straight from the
-// segment ring.)
+// Predelay epochs.  The reference adds every call's N_ref-long contribution to
+// its accumulator at the predelay current at THAT call (conv.cu:411-415): after
+// a predelay change the blocks already played keep ringing out at the old
+// offset.  When the predelay changes, the host renders everything the old
+// blocks still owe into two residual rings indexed by absolute OUTPUT sample
+// and restarts the live pipeline from silence (k_flush_ola / k_flush_fix):
+//   mac : the partition sums (of this engine's partition shard), already delayed
+//   fix : Q1/Q2 window terms minus Q8 drops of the old blocks
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T, float* __restrict__ lin) {
+struct Retired {
+    float* mac;   // [2][rr]
+    float* fix;   // [2][rr]
+    int rr;
+    int64_t end;  // the rings hold output samples tau < end (0: nothing retired)
+    int64_t b0;   // first block of the live epoch; older blocks live in the rings
+};
+
+__device__ __forceinline__ float2 retired_at(const float* __restrict__ ring, int rr, int64_t tau) {
+    return make_float2(ring[(size_t)(tau & (rr - 1))], ring[(size_t)rr + (tau & (rr - 1))]);
+}
+
+// Wet sample of this engine delayed by the live predelay: writes the thread's own
+// overlap-added sample to the wet ring (history for later batches / periods) and
+// returns sample tau - predelay (from this batch's segments when it is that young).
+__device__ __forceinline__ float2 delayed_wet(const float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet, int wr,
+                                              int T, int t, int m, int64_t tau0, int64_t predelay) {
+    const int64_t i = (int64_t)t * MC_B + m;
+    const int64_t tau = tau0 + i;
+    const int64_t u = tau - predelay;
+    const float2 own = batch_wet(seg, sr, seg0, t, m);
+    wet[(size_t)(tau & (wr - 1))] = own.x;
+    wet[(size_t)wr + (tau & (wr - 1))] = own.y;
+    if (u >= tau0) {  // delayed sample lies in this batch: not in the ring yet
+        const int64_t j = u - tau0;
+        return (j == i) ? own : batch_wet(seg, sr, seg0, (int)(j >> 8), (int)(j & 255));
+    }
+    if (u >= 0) return make_float2(wet[(size_t)(u & (wr - 1))], wet[(size_t)wr + (u & (wr - 1))]);
+    return make_float2(0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// K4 (sharded operation only): this shard's overlap-added, predelayed wet
+// signal plus what its retired epochs owe, into the caller's linear partial
+// buffer [2][T*256] that goes into the cross-GPU sum.  (A single engine needs
+// no such pass: k_post does the same straight from the segment ring.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T, float* __restrict__ wet, int wr,
+                                             int64_t tabs0, int64_t predelay, Retired ret, float* __restrict__ lin) {
     const int t = blockIdx.x, m = threadIdx.x;
-    const float2 w = batch_wet(seg, sr, seg0, nullptr, T, t, m);
+    const int64_t tau = (tabs0 + t) * MC_B + m;
+    float2 w = delayed_wet(seg, sr, seg0, wet, wr, T, t, m, tabs0 * MC_B, predelay);
+    if (tau < ret.end) {
+        const float2 r = retired_at(ret.mac, ret.rr, tau);
+        w.x += r.x;
+        w.y += r.y;
+    }
     lin[(size_t)t * MC_B + m] = w.x;
     lin[(size_t)T * MC_B + (size_t)t * MC_B + m] = w.y;
 }
@@ -681,14 +726,17 @@ struct TailDrop {
 __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
                                           const BlockParams* __restrict__ ptab, int pstride, int rc,
                                           const float* __restrict__ cur1, const float* __restrict__ cur2, float& dl,
-                                          float& dr, int m = 1) {
+                                          float& dr, int m, int64_t blo, int64_t bhi) {
+    // blo..bhi: blocks of the predelay epoch this pass accounts for (inclusive)
     dl = dr = 0.f;
     const int64_t v = tau - n_ref;
     if (v < 0) return;
     // blocks of every call (m blocks each) that started at or before tau - n_ref
-    const int64_t hi_tb = ((v >> 8) / m + 1) * m - 1;
+    int64_t hi_tb = ((v >> 8) / m + 1) * m - 1;
     const int64_t lo = tau - pd - 254 - td.lmax;
-    const int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
+    int64_t lo_tb = lo <= 0 ? 0 : ((lo + 255) >> 8);
+    if (lo_tb < blo) lo_tb = blo;
+    if (hi_tb > bhi) hi_tb = bhi;
     for (int64_t tb = lo_tb; tb <= hi_tb; tb++) {
         const int64_t s = tau - pd - (tb << 8);  // position inside block tb's own contribution
         const int64_t rel = tb - (tau0 >> 8);
@@ -753,53 +801,61 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
-                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td, int pm) {
+                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td, int pm, Retired ret) {
     // pm = blocks per reference call (JACK period / 256): Q1/Q2/Q8 windows are measured from the call start
     const int t = blockIdx.x, m = threadIdx.x;
     const int64_t i = (int64_t)t * MC_B + m;
     const int64_t tau0 = tabs0 * MC_B;
     const int64_t tau = tau0 + i;
     const int64_t u = tau - predelay;
-    // this thread's own sample goes to the wet ring (history for later batches / periods)
-    const float2 own = batch_wet(seg, sr, seg0, lin, T, t, m);
-    wet[(size_t)(tau & (wr - 1))] = own.x;
-    wet[(size_t)wr + (tau & (wr - 1))] = own.y;
-    float wl = 0.f, wr_ = 0.f;
-    if (u >= tau0) {  // delayed sample lies in this batch: not in the ring yet
-        const int64_t j = u - tau0;
-        const float2 w = (j == i) ? own : batch_wet(seg, sr, seg0, lin, T, (int)(j >> 8), (int)(j & 255));
+    float wl, wr_;
+    if (lin) {  // shards: the sum over ranks of k_ola's output (predelay and retired partition sums included)
+        wl = lin[i];
+        wr_ = lin[(size_t)T * MC_B + i];
+    } else {
+        const float2 w = delayed_wet(seg, sr, seg0, wet, wr, T, t, m, tau0, predelay);
         wl = w.x;
         wr_ = w.y;
-    } else if (u >= 0) {
-        wl = wet[(size_t)(u & (wr - 1))];
-        wr_ = wet[(size_t)wr + (u & (wr - 1))];
+        if (tau < ret.end) {
+            const float2 r = retired_at(ret.mac, ret.rr, tau);
+            wl += r.x;
+            wr_ += r.y;
+        }
+    }
+    if (tau < ret.end) {
+        const float2 r = retired_at(ret.fix, ret.rr, tau);
+        wl += r.x;
+        wr_ += r.y;
     }
     double cl = 0.0, cr = 0.0;
     if (compat && u >= 0) {
-        // calls q (pm blocks each) with predelay <= tau - q*period < n_ref (shift by predelay, cut at n_ref: Q8);
-        // prefix sums are per block, so a call ends at block (q + 1) pm - 1
+        // calls q (pm blocks each) of the live epoch with predelay <= tau - q*period < n_ref (shift by predelay, cut
+        // at n_ref: Q8); prefix sums are per block, so a call ends at block (q + 1) pm - 1
         const int64_t thi = ((u >> 8) / pm + 1) * pm - 1;
         const int64_t v = tau - n_ref;
-        const int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
-        const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
-        double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
-        if (tlo >= 0) {
-            const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
-            d0 -= b[0];
-            d1 -= b[1];
-            q0 -= b[2];
-            q1 -= b[3];
+        int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
+        if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
+        if (thi > tlo) {
+            const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
+            double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
+            if (tlo >= 0) {
+                const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
+                d0 -= b[0];
+                d1 -= b[1];
+                q0 -= b[2];
+                q1 -= b[3];
+            }
+            const double sg = (u & 1) ? -1.0 : 1.0;
+            cl = d0 + sg * q0;
+            cr = d1 + sg * q1;
         }
-        const double sg = (u & 1) ? -1.0 : 1.0;
-        cl = d0 + sg * q0;
-        cr = d1 + sg * q1;
     }
     const BlockParams& bp = ptab[(int64_t)t * pstride];
     const float x1 = in1[i], x2 = in2[i];
     write_history(td, tau, tabs0 + t, m, x1, x2, bp, rc);
     if (td.on) {
         float dl, dr;
-        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm);
+        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
         wl -= dl;
         wr_ -= dr;
     }
@@ -807,6 +863,73 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
     outL[i] = vl + x1 * bp.d[0] + x2 * bp.d[1];
     outR[i] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+}
+
+// ---------------------------------------------------------------------------
+// Predelay change (host: retire_epoch).  k_flush_ola: the partition sums the
+// old blocks still owe, rendered by a run of the pipeline over silent input,
+// are added to the residual ring at their OLD predelay; what the reference
+// would cut at n_ref after the shift (Q8) is not written.  k_flush_ring: wet
+// samples of the old blocks that the old predelay has not released yet move
+// from the wet ring to the residual ring.  k_flush_fix: the
+// Q1/Q2 window terms of the old blocks for future output samples, minus their
+// Q8 drops.  Both accumulate: tails of earlier epochs may still be pending.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flush_ola(const float* __restrict__ seg, int sr, int seg0, int T, int64_t tabs0,
+                                                   int64_t predelay_old, float* __restrict__ res, int rr, int64_t end) {
+    const int t = blockIdx.x, m = threadIdx.x;
+    const float2 w = batch_wet(seg, sr, seg0, t, m);
+    const int64_t tau = (tabs0 + t) * MC_B + m + predelay_old;
+    if (tau < end) {
+        res[(size_t)(tau & (rr - 1))] += w.x;
+        res[(size_t)rr + (tau & (rr - 1))] += w.y;
+    }
+}
+
+// wet samples already computed under the old predelay but not yet played (the last predelay_old samples of the ring)
+__global__ __launch_bounds__(256) void k_flush_ring(const float* __restrict__ wet, int wr, int64_t tau_begin, int64_t predelay_old,
+                                                    float* __restrict__ res, int rr, int64_t end) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tau = tau_begin + k, u = tau - predelay_old;
+    if (k >= predelay_old || u < 0 || tau >= end) return;
+    res[(size_t)(tau & (rr - 1))] += wet[(size_t)(u & (wr - 1))];
+    res[(size_t)rr + (tau & (rr - 1))] += wet[(size_t)wr + (u & (wr - 1))];
+}
+
+__global__ __launch_bounds__(256) void k_flush_fix(const double* __restrict__ cring, int rc, float* __restrict__ res, int rr,
+                                                   int64_t tau_begin, int64_t end, int64_t blo, int64_t bhi,
+                                                   int64_t predelay_old, int64_t n_ref, int compat, TailDrop td, int pm) {
+    // blo..bhi (inclusive): the blocks of the epoch being retired
+    const int64_t tau = tau_begin + (int64_t)blockIdx.x * MC_B + threadIdx.x;
+    if (tau >= end) return;
+    const int64_t u = tau - predelay_old;
+    double cl = 0.0, cr = 0.0;
+    if (compat && u >= 0) {
+        int64_t thi = ((u >> 8) / pm + 1) * pm - 1;
+        if (thi > bhi) thi = bhi;
+        const int64_t v = tau - n_ref;
+        int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
+        if (tlo < blo - 1) tlo = blo - 1;
+        if (thi > tlo) {
+            const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
+            double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
+            if (tlo >= 0) {
+                const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
+                d0 -= b[0];
+                d1 -= b[1];
+                q0 -= b[2];
+                q1 -= b[3];
+            }
+            const double sg = (u & 1) ? -1.0 : 1.0;
+            cl = d0 + sg * q0;
+            cr = d1 + sg * q1;
+        }
+    }
+    float dl = 0.f, dr = 0.f;
+    if (td.on)  // every block of the epoch is history: no current batch (T = 0, tau0 beyond reach)
+        tail_drop(td, tau, INT64_MAX, 0, predelay_old, n_ref, nullptr, 0, rc, nullptr, nullptr, dl, dr, pm, blo, bhi);
+    res[(size_t)(tau & (rr - 1))] += (float)(cl - (double)dl);
+    res[(size_t)rr + (tau & (rr - 1))] += (float)(cr - (double)dr);
 }
 
 // ---------------------------------------------------------------------------
@@ -836,7 +959,8 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                                                int rc, VoiceSums vs, double inv_n, int compat, int64_t tabs0,
                                                int64_t predelay, int64_t n_ref, float* __restrict__ outL,
                                                float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td,
-                                               uint2* __restrict__ fdl16, unsigned* __restrict__ done_flag, unsigned seq) {
+                                               uint2* __restrict__ fdl16, unsigned* __restrict__ done_flag, unsigned seq,
+                                               Retired ret) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
     __shared__ float4 s_x[MC_NB];  // raw spectra of the new block {X1, X2}
@@ -991,31 +1115,39 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
                 wr_ = wet[(size_t)wr + (u & (wr - 1))];
             }
         }
+        if (tau < ret.end) {  // what blocks played under an earlier predelay still owe
+            const float2 ra = retired_at(ret.mac, ret.rr, tau), rb = retired_at(ret.fix, ret.rr, tau);
+            wl += ra.x + rb.x;
+            wr_ += ra.y + rb.y;
+        }
         double cl = 0.0, cr = 0.0;
         if (compat && u >= 0) {
             const int64_t thi = u >> 8;
             const int64_t vv = tau - n_ref;
-            const int64_t tlo = vv >= 0 ? (vv >> 8) : -1;
-            double a[4];
-            if (thi == tabs0) {
-                for (int c = 0; c < 4; c++) a[c] = s_c[c];
-            } else {
-                const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
-                for (int c = 0; c < 4; c++) a[c] = pa[c];
+            int64_t tlo = vv >= 0 ? (vv >> 8) : -1;
+            if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
+            if (thi > tlo) {
+                double a[4];
+                if (thi == tabs0) {
+                    for (int c = 0; c < 4; c++) a[c] = s_c[c];
+                } else {
+                    const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
+                    for (int c = 0; c < 4; c++) a[c] = pa[c];
+                }
+                if (tlo >= 0) {
+                    const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
+                    for (int c = 0; c < 4; c++) a[c] -= b[c];
+                }
+                const double sg = (u & 1) ? -1.0 : 1.0;
+                cl = a[0] + sg * a[2];
+                cr = a[1] + sg * a[3];
             }
-            if (tlo >= 0) {
-                const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
-                for (int c = 0; c < 4; c++) a[c] -= b[c];
-            }
-            const double sg = (u & 1) ? -1.0 : 1.0;
-            cl = a[0] + sg * a[2];
-            cr = a[1] + sg * a[3];
         }
         const float x1 = s_in[0][m], x2 = s_in[1][m];
         write_history(td, tau, tabs0, m, x1, x2, bp, rc);
         if (td.on) {
             float dl, dr;
-            tail_drop(td, tau, tabs0 * MC_B, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr);
+            tail_drop(td, tau, tabs0 * MC_B, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, 1, ret.b0, INT64_MAX);
             wl -= dl;
             wr_ -= dr;
         }

@@ -84,6 +84,12 @@ struct mc_engine {
     float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
     double* d_ctot = nullptr;   // [ceil(Tmax/256)][4] chunk totals of the Q1/Q2 prefix sums
+    // predelay epochs: what blocks played under earlier predelays still owe, by absolute output sample
+    float *d_res_mac = nullptr, *d_res_fix = nullptr;  // [2][rr] each
+    int rr = 0;
+    uint64_t res_end = 0;     // the rings hold output samples < res_end
+    uint64_t epoch_b0 = 0;    // first block of the live epoch
+    uint64_t cur_delay = 0;   // its predelay
     float* d_xhist = nullptr;   // [2][xr] input history (Q8 pass)
     float4* d_gring = nullptr;  // [MC_MAXV][rc] wet gains of past blocks (Q8 pass)
     int xr = 0;
@@ -192,7 +198,10 @@ int zero_state(mc_engine* e) {
     HIP_TRY(hipMemsetAsync(e->d_cring, 0, sizeof(double) * 4 * (size_t)e->rc, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_xhist, 0, sizeof(float) * 2 * (size_t)e->xr, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_gring, 0, sizeof(float4) * (size_t)MC_MAXV * e->rc, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_res_mac, 0, sizeof(float) * 2 * (size_t)e->rr, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_res_fix, 0, sizeof(float) * 2 * (size_t)e->rr, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->res_end = e->epoch_b0 = e->cur_delay = 0;
     for (int i = 0; i < 2; i++)
         for (int v = 0; v < MC_MAXV; v++) e->voice[i][v] = mc_engine::VoiceSlot();
     for (int v = 0; v < MC_MAXV; v++) {
@@ -325,10 +334,8 @@ const IrEntry* any_ir(const mc_engine* e) {
     return nullptr;
 }
 
-int stage_params(mc_engine* e, int T, Staged* st) {
-    const int bslot = (int)(e->batch_seq % kPipe);
-    BlockParams* d_ptab = e->d_ptab + (size_t)bslot * e->Tmax;
-    mc_cc_value cc[2];
+// cc[i].value as the call sees it (conv.cu reads the public fields once per onProcess)
+int sample_params(mc_engine* e, mc_cc_value (&cc)[2]) {
     {
         std::lock_guard<std::mutex> lk(e->pmu);
         cc[0] = e->cc[0];
@@ -339,6 +346,45 @@ int stage_params(mc_engine* e, int T, Staged* st) {
             return fail(MC_ERR_STATE, "half %d selects IR %llu which is not loaded", i, (unsigned long long)cc[i].select);
     }
     if (cc[0].predelay > MC_MAX_PREDELAY) return fail(MC_ERR_ARG, "predelay %llu > %d", (unsigned long long)cc[0].predelay, MC_MAX_PREDELAY);
+    return MC_OK;
+}
+
+// The voices that can still be heard at block e->t_front, as the MAC sees them
+int collect_voices(const mc_engine* e, const BlockParams* first, ActiveVoice* act, int (&vir)[2][MC_MAXV], VoiceSums* vs) {
+    if (vs) std::memset(vs, 0, sizeof(*vs));
+    const IrEntry* fallback = any_ir(e);
+    int nact = 0;
+    for (int v = 0; v < MC_MAXV; v++) {
+        const IrEntry* ir[2];
+        for (int i = 0; i < 2; i++) {
+            const int idx = e->voice[i][v].ir;
+            vir[i][v] = (idx >= 0 && e->irs[idx].d_H) ? idx : -1;
+            ir[i] = vir[i][v] >= 0 ? &e->irs[idx] : nullptr;
+            if (ir[i] && vs) {
+                for (int c = 0; c < 2; c++) {
+                    vs->sig[v][i][c] = ir[i]->sums[c];
+                    vs->alp[v][i][c] = ir[i]->sums[2 + c];
+                }
+            }
+        }
+        if (!ir[0] && !ir[1]) continue;
+        ActiveVoice a;
+        a.v = v;
+        a.ir0 = ir[0] ? ir[0] : (ir[1] ? ir[1] : fallback);  // a missing half has zero gains; any valid spectra do
+        a.ir1 = ir[1] ? ir[1] : a.ir0;
+        a.p_end = round_up(std::max(ir[0] ? ir[0]->P : 0, ir[1] ? ir[1]->P : 0), 16);
+        // sounding in this batch's windows?  (last non-zero gain not older than the sweep)
+        if (!e->voice_ever[v] || e->last_nz_voice[v] + (uint64_t)a.p_end < e->t_front) continue;
+        a.uniform = first && e->gain_change_block[v] + (uint64_t)a.p_end <= e->t_front;
+        a.ugain = first ? make_float4(first->g[v][0], first->g[v][1], first->g[v][2], first->g[v][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        act[nact++] = a;
+    }
+    return nact;
+}
+
+int stage_params(mc_engine* e, int T, mc_cc_value (&cc)[2], Staged* st) {
+    const int bslot = (int)(e->batch_seq % kPipe);
+    BlockParams* d_ptab = e->d_ptab + (size_t)bslot * e->Tmax;
 
     BlockParams* tab;
     int ntab;
@@ -372,34 +418,7 @@ int stage_params(mc_engine* e, int T, Staged* st) {
     st->ctx.pstride = pstride;
     st->ctx.predelay = cc[0].predelay;
     st->ctx.slot = bslot;
-    std::memset(&st->ctx.vs, 0, sizeof(st->ctx.vs));
-    const IrEntry* fallback = any_ir(e);
-    st->nact = 0;
-    for (int v = 0; v < MC_MAXV; v++) {
-        const IrEntry* ir[2];
-        for (int i = 0; i < 2; i++) {
-            const int idx = e->voice[i][v].ir;
-            st->ctx.vir[i][v] = (idx >= 0 && e->irs[idx].d_H) ? idx : -1;
-            ir[i] = st->ctx.vir[i][v] >= 0 ? &e->irs[idx] : nullptr;
-            if (ir[i]) {
-                for (int c = 0; c < 2; c++) {
-                    st->ctx.vs.sig[v][i][c] = ir[i]->sums[c];
-                    st->ctx.vs.alp[v][i][c] = ir[i]->sums[2 + c];
-                }
-            }
-        }
-        if (!ir[0] && !ir[1]) continue;
-        ActiveVoice a;
-        a.v = v;
-        a.ir0 = ir[0] ? ir[0] : (ir[1] ? ir[1] : fallback);  // a missing half has zero gains; any valid spectra do
-        a.ir1 = ir[1] ? ir[1] : a.ir0;
-        a.p_end = round_up(std::max(ir[0] ? ir[0]->P : 0, ir[1] ? ir[1]->P : 0), 16);
-        // sounding in this batch's windows?  (last non-zero gain not older than the sweep)
-        if (!e->voice_ever[v] || e->last_nz_voice[v] + (uint64_t)a.p_end < e->t_front) continue;
-        a.uniform = e->gain_change_block[v] + (uint64_t)a.p_end <= e->t_front;
-        a.ugain = make_float4(tab[0].g[v][0], tab[0].g[v][1], tab[0].g[v][2], tab[0].g[v][3]);
-        st->act[st->nact++] = a;
-    }
+    st->nact = collect_voices(e, &tab[0], st->act, st->ctx.vir, &st->ctx.vs);
     return MC_OK;
 }
 
@@ -465,6 +484,167 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
 #undef MC_LAUNCH_STREAM
 }
 
+// Where k_inv finds the partition sums of a batch
+struct MacOut {
+    const float4* ysrc;
+    int64_t sk, stt, sc;
+    int nsum;
+    int swept;
+    bool resident;
+};
+
+// Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
+// per_slot_gains: the batch's blocks (or the window) do not share one set of gains.
+int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T, int slot0, MacOut* mo) {
+    mo->resident = T >= e->stream_threshold && !e->half;
+    mo->swept = 0;
+    mo->sc = 1;
+    if (mo->resident) {
+        // short batches: split the partition range so that the launch has ~2048 workgroups
+        const int tiles = (T + 255) / 256;
+        const int psplit = std::max(1, std::min(8, 8 / tiles));
+        const int tcap = psplit > 1 ? tiles * 256 : e->Tmax;  // plane stride of Y (planes summed by k_inv)
+        int launched = 0;
+        for (int a = 0; a < nact; a++) {
+            const ActiveVoice& av = act[a];
+            int p_begin, p_end;
+            partition_range(e, av.p_end, &p_begin, &p_end);
+            if (p_end <= p_begin) continue;
+            const int pchunk = round_up((p_end - p_begin + psplit - 1) / psplit, 16);
+            const dim3 grid(MC_NB * tiles * psplit);
+            const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
+            if (av.uniform && !per_slot_gains)
+                hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
+                                   psplit, pchunk);
+            else
+                hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
+                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
+                                   psplit, pchunk);
+            launched++;
+            mo->swept = std::max(mo->swept, p_end - p_begin);
+        }
+        if (!launched) HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * tcap * psplit, e->stream));
+        mo->ysrc = e->d_Y;
+        mo->sk = tcap;
+        mo->stt = 1;
+        mo->nsum = psplit;
+        mo->sc = (int64_t)MC_NB * tcap;
+    } else {
+        // streaming: one set of chunk partials per sounding voice, all added by k_inv
+        int nv = 0;
+        ActiveVoice list[MC_MAXV];
+        int pb[MC_MAXV], pe[MC_MAXV];
+        for (int a = 0; a < nact; a++) {
+            partition_range(e, act[a].p_end, &pb[nv], &pe[nv]);
+            if (pe[nv] <= pb[nv]) continue;
+            list[nv] = act[a];
+            if (per_slot_gains) list[nv].uniform = false;
+            nv++;
+        }
+        mo->nsum = std::max(1, nv) * e->nchunk;
+        if (!nv) HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)T * MC_NB * mo->nsum, e->stream));
+        for (int a = 0; a < nv; a++) {
+            launch_mac_stream(e, list[a], pb[a], pe[a], T, slot0, mo->nsum, a * e->nchunk);
+            mo->swept = std::max(mo->swept, pe[a] - pb[a]);
+        }
+        mo->ysrc = e->d_part;
+        mo->sk = mo->nsum;
+        mo->stt = (int64_t)MC_NB * mo->nsum;
+    }
+    return MC_OK;
+}
+
+Retired make_retired(const mc_engine* e) {
+    Retired r;
+    r.mac = e->d_res_mac;
+    r.fix = e->d_res_fix;
+    r.rr = e->rr;
+    r.end = (int64_t)e->res_end;
+    r.b0 = (int64_t)e->epoch_b0;
+    return r;
+}
+
+int zero_ring_range(mc_engine* e, float* ring, uint64_t from, uint64_t to) {
+    // samples [from, to) of a [2][rr] ring indexed by absolute sample; to - from <= rr
+    if (to <= from) return MC_OK;
+    const uint64_t rr = (uint64_t)e->rr;
+    const uint64_t a = from & (rr - 1), n = to - from;
+    const uint64_t n1 = std::min(n, rr - a);
+    for (int c = 0; c < 2; c++) {
+        HIP_TRY(hipMemsetAsync(ring + (size_t)c * rr + a, 0, sizeof(float) * n1, e->stream));
+        if (n > n1) HIP_TRY(hipMemsetAsync(ring + (size_t)c * rr, 0, sizeof(float) * (n - n1), e->stream));
+    }
+    return MC_OK;
+}
+
+// The predelay of the next call differs from the live epoch's.  The reference shifts every call's contribution
+// by the predelay current at that call (conv.cu:411-415), so the blocks played so far keep their old offset:
+// render what they still owe (partition sums over silent input, Q1/Q2 window terms, Q8 drops) into the
+// residual rings and restart the live pipeline from silence under the new predelay.
+int retire_epoch(mc_engine* e, uint64_t new_delay) {
+    if (new_delay == e->cur_delay) return MC_OK;
+    if (e->t_front == e->epoch_b0) {  // nothing has been played under the old value
+        e->cur_delay = new_delay;
+        return MC_OK;
+    }
+    if (e->pipe_count) return fail(MC_ERR_STATE, "predelay changed while a batch awaits mc_finish_batch_device");
+    const uint64_t b0 = e->t_front, bs = e->epoch_b0, d_old = e->cur_delay;
+    // the latest old call started at block b0 - pm; the reference cuts its contribution n_ref samples later
+    const uint64_t new_end = (b0 - (uint64_t)e->pm) * MC_B + e->cfg.n_ref;
+    const uint64_t pending_from = std::max<uint64_t>(e->res_end, b0 * MC_B);
+    int rc = zero_ring_range(e, e->d_res_mac, pending_from, new_end);
+    if (!rc) rc = zero_ring_range(e, e->d_res_fix, pending_from, new_end);
+    if (rc) return rc;
+
+    ActiveVoice act[MC_MAXV];
+    int vir[2][MC_MAXV];
+    const int nact = collect_voices(e, nullptr, act, vir, nullptr);
+    int F = 0;  // blocks over which the old blocks still ring: the longest sounding IR
+    for (int a = 0; a < nact; a++) F = std::max(F, act[a].p_end);
+    // nothing beyond the cut is kept
+    F = (int)std::min<uint64_t>((uint64_t)F, (new_end - b0 * MC_B + MC_B - 1) / MC_B);
+    if (d_old)
+        hipLaunchKernelGGL(k_flush_ring, dim3((unsigned)((d_old + 255) / 256)), dim3(256), 0, e->stream, e->d_wet, e->wr,
+                           (int64_t)(b0 * MC_B), (int64_t)d_old, e->d_res_mac, e->rr, (int64_t)new_end);
+    uint64_t tv = b0;
+    while (F > 0) {
+        int Tc = std::min(F, e->Tmax);
+        if (!(Tc >= e->stream_threshold && !e->half)) Tc = std::min(Tc, e->Tstream);
+        const int slot0 = (int)(tv & (uint64_t)(e->ring - 1)), seg0 = (int)(tv & (uint64_t)(e->sr - 1));
+        // silent blocks into the delay line (n_frames = 0: the inputs are never read)
+        hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, (const float*)nullptr,
+                           (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
+                           (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16);
+        MacOut mo;
+        rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_inv, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
+                           mo.sc, Tc, e->d_seg, e->sr, seg0, e->d_tw);
+        hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, Tc, (int64_t)tv, (int64_t)d_old,
+                           e->d_res_mac, e->rr, (int64_t)new_end);
+        tv += (uint64_t)Tc;
+        F -= Tc;
+    }
+    {
+        const uint64_t n = new_end - b0 * MC_B;
+        hipLaunchKernelGGL(k_flush_fix, dim3((unsigned)((n + MC_B - 1) / MC_B)), dim3(256), 0, e->stream, e->d_cring, e->rc,
+                           e->d_res_fix, e->rr, (int64_t)(b0 * MC_B), (int64_t)new_end, (int64_t)bs, (int64_t)b0 - 1, (int64_t)d_old,
+                           (int64_t)e->cfg.n_ref, (int)e->cfg.compat, make_taildrop(e, vir, d_old), e->pm);
+    }
+    HIP_TRY(hipGetLastError());
+    // the live pipeline restarts from silence: the old blocks are accounted for
+    HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
+    if (e->d_fdl16) HIP_TRY(hipMemsetAsync(e->d_fdl16, 0, sizeof(uint2) * (size_t)MC_NB * e->ring, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_seg, 0, sizeof(float) * (size_t)e->sr * 2 * FFT_N, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_wet, 0, sizeof(float) * 2 * (size_t)e->wr, e->stream));
+    e->res_end = new_end;
+    e->epoch_b0 = b0;
+    e->cur_delay = new_delay;
+    e->spec_valid = false;
+    return MC_OK;
+}
+
 // forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial
 int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin) {
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
@@ -472,7 +652,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
     Staged st;
     {
-        int rc = stage_params(e, T, &st);
+        mc_cc_value cc[2];
+        int rc = sample_params(e, cc);
+        if (!rc) rc = retire_epoch(e, cc[0].predelay);
+        if (!rc) rc = stage_params(e, T, cc, &st);
         if (rc) return rc;
     }
     e->pipe[(e->pipe_head + e->pipe_count) % kPipe] = st.ctx;
@@ -487,7 +670,6 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // K1
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16);
-    const bool resident = T >= e->stream_threshold && !e->half;
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
     if (e->ktiming) {
         if (e->kev_n == kEvPool) {
@@ -499,73 +681,24 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         e->kev_blocks[e->kev_n] = (uint32_t)T;
         HIP_TRY(hipEventRecord(*k0, e->stream));
     }
-    int64_t sk, stt;
-    int nsum, swept = 0, launched = 0;
-    const float4* ysrc;
-    int64_t sc = 1;
-    if (resident) {
-        // short batches: split the partition range so that the launch has ~2048 workgroups
-        const int tiles = (T + 255) / 256;
-        const int psplit = std::max(1, std::min(8, 8 / tiles));
-        const int tcap = psplit > 1 ? tiles * 256 : e->Tmax;  // plane stride of Y (planes summed by k_inv)
-        for (int a = 0; a < st.nact; a++) {
-            const ActiveVoice& av = st.act[a];
-            int p_begin, p_end;
-            partition_range(e, av.p_end, &p_begin, &p_end);
-            if (p_end <= p_begin) continue;
-            const int pchunk = round_up((p_end - p_begin + psplit - 1) / psplit, 16);
-            const dim3 grid(MC_NB * tiles * psplit);
-            const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
-            if (av.uniform && pstride == 0)
-                hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
-                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk);
-            else
-                hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
-                                   p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk);
-            launched++;
-            swept = std::max(swept, p_end - p_begin);
-        }
-        if (!launched) HIP_TRY(hipMemsetAsync(e->d_Y, 0, sizeof(float4) * (size_t)MC_NB * tcap * psplit, e->stream));
-        ysrc = e->d_Y;
-        sk = tcap;
-        stt = 1;
-        nsum = psplit;
-        sc = (int64_t)MC_NB * tcap;
-    } else {
-        // streaming: one set of chunk partials per sounding voice, all added by k_inv
-        int nv = 0;
-        ActiveVoice list[MC_MAXV];
-        int pb[MC_MAXV], pe[MC_MAXV];
-        for (int a = 0; a < st.nact; a++) {
-            partition_range(e, st.act[a].p_end, &pb[nv], &pe[nv]);
-            if (pe[nv] <= pb[nv]) continue;
-            list[nv] = st.act[a];
-            if (pstride != 0) list[nv].uniform = false;
-            nv++;
-        }
-        nsum = std::max(1, nv) * e->nchunk;
-        if (!nv) HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)T * MC_NB * nsum, e->stream));
-        for (int a = 0; a < nv; a++) {
-            launch_mac_stream(e, list[a], pb[a], pe[a], T, slot0, nsum, a * e->nchunk);
-            swept = std::max(swept, pe[a] - pb[a]);
-        }
-        ysrc = e->d_part;
-        sk = nsum;
-        stt = (int64_t)MC_NB * nsum;
+    MacOut mo;
+    {
+        int rc = launch_mac_batch(e, st.act, st.nact, pstride != 0, T, slot0, &mo);
+        if (rc) return rc;
     }
     if (e->ktiming) {
         HIP_TRY(hipEventRecord(*k1, e->stream));
         e->kev_n++;
-        e->ks.resident = resident ? 1 : 0;
-        e->ks.partitions = (uint32_t)swept;
+        e->ks.resident = mo.resident ? 1 : 0;
+        e->ks.partitions = (uint32_t)mo.swept;
     }
 
     // K3 (+ K4 for shards)
-    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, ysrc, sk, stt, nsum, sc, T, e->d_seg,
-                       e->sr, seg0, e->d_tw);
-    if (lin) hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, lin);
+    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum, mo.sc, T,
+                       e->d_seg, e->sr, seg0, e->d_tw);
+    if (lin)
+        hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, e->d_wet, e->wr, (int64_t)e->t_front,
+                           (int64_t)st.ctx.predelay, make_retired(e), lin);
     HIP_TRY(hipGetLastError());
     e->pipe_count++;
     e->batch_seq++;
@@ -594,7 +727,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
                            e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
                            (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
-                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm);
+                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e));
         HIP_TRY(hipGetLastError());
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
@@ -612,7 +745,10 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
     Staged st;
     {
-        int rc = stage_params(e, 1, &st);
+        mc_cc_value cc[2];
+        int rc = sample_params(e, cc);
+        if (!rc) rc = retire_epoch(e, cc[0].predelay);
+        if (!rc) rc = stage_params(e, 1, cc, &st);
         if (rc) return rc;
     }
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
@@ -690,7 +826,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                        e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, seg0, e->d_wet, e->wr,
                        e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,
                        (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq);
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq, make_retired(e));
     HIP_TRY(hipGetLastError());
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
@@ -854,6 +990,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
     ENG_TRY(hipMalloc(&e->d_ctot, sizeof(double) * 4 * (size_t)((e->Tmax + 255) / 256 + 1)));
+    e->rr = (int)next_pow2(cfg->n_ref);
+    ENG_TRY(hipMalloc(&e->d_res_mac, sizeof(float) * 2 * (size_t)e->rr));
+    ENG_TRY(hipMalloc(&e->d_res_fix, sizeof(float) * 2 * (size_t)e->rr));
     e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B + MC_MAX_PREDELAY + 1024);
     ENG_TRY(hipMalloc(&e->d_xhist, sizeof(float) * 2 * (size_t)e->xr));
     ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
@@ -909,6 +1048,8 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_wet);
     (void)hipFree(e->d_cring);
     (void)hipFree(e->d_ctot);
+    (void)hipFree(e->d_res_mac);
+    (void)hipFree(e->d_res_fix);
     (void)hipFree(e->d_xhist);
     (void)hipFree(e->d_gring);
     (void)hipFree(e->d_ptab);

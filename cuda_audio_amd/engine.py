@@ -178,7 +178,18 @@ class Convolution:
         check(self._L.mc_sync(self._h))
 
     def set_stream(self, stream_ptr):
+        """hipStream_t as an int; None / 0 = the engine's own non-blocking stream (NOT ordered with the default
+        stream: use `use_torch_stream` when the buffers are torch tensors)."""
         check(self._L.mc_set_stream(self._h, stream_ptr))
+
+    def use_torch_stream(self, stream=None):
+        """Launch on `stream` (default: torch's current stream) so that the engine is ordered with the torch ops
+        and collectives that produce and consume its device buffers.  torch reports the default stream as handle 0,
+        which mc_set_stream reads as "own stream": MC_STREAM_DEFAULT (hipStreamLegacy) names it explicitly."""
+        import torch
+
+        ptr = (stream or torch.cuda.current_stream()).cuda_stream
+        check(self._L.mc_set_stream(self._h, ptr if ptr else 1))
 
     # -- introspection ----------------------------------------------------------
     def num_irs(self):

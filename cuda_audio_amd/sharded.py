@@ -47,7 +47,7 @@ class HipShard:
             raise ValueError("empty shard: use fewer ranks than partitions / 16")
         self.conv = Convolution("shard", fft_size, max_batch=max_batch, device=device, compat=compat,
                                 part_begin=pb, part_end=pe)
-        self.conv.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.conv.use_torch_stream()
 
     def prepare(self, idx, lr, nframes=1024):
         self.conv.prepare(idx, lr, nframes)

@@ -125,9 +125,11 @@ int mc_process_batch(mc_engine *e, const float *in1, const float *in2, float *ou
 int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
                             uint64_t nblocks);
 /* Sharded operation: d_partial receives this engine's share of the wet signal,
- * 2*nblocks*256 floats ([L | R], pre-predelay); after the caller has summed the
- * partials of all shards (RCCL reduce / all-reduce), mc_finish_batch_device applies
- * predelay, Q1/Q2 terms, clamp and dry mix.  Every shard must see the same input.
+ * 2*nblocks*256 floats ([L | R], overlap-added and already shifted by the predelay);
+ * after the caller has summed the partials of all shards (RCCL reduce / all-reduce),
+ * mc_finish_batch_device applies Q1/Q2 terms, Q8, clamp and dry mix.  Every shard must
+ * see the same input and parameters.  A predelay change must not arrive while a batch
+ * is between its partial and its finish (MC_ERR_STATE).
  * Up to two batches may be between their partial and their finish (finishes
  * retire batches in order), so the reduce of batch k can overlap the MAC of
  * batch k+1.  A rank that does not need the output (non-root of a reduce)
@@ -138,7 +140,12 @@ int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2,
                            float *d_outL, float *d_outR, uint64_t nblocks);
 
 int mc_sync(mc_engine *e);
-int mc_set_stream(mc_engine *e, void *hip_stream); /* NULL = engine-owned stream */
+/* hip_stream is a hipStream_t.  NULL selects the engine's own stream, which is NON-BLOCKING: it is not ordered
+ * with HIP's default stream.  A caller whose buffers are produced or consumed on the default stream (PyTorch's
+ * current stream unless one is set) must pass that stream explicitly - MC_STREAM_DEFAULT, HIP's hipStreamLegacy
+ * handle - or order the two with mc_sync / events. */
+#define MC_STREAM_DEFAULT ((void *)1)
+int mc_set_stream(mc_engine *e, void *hip_stream);
 void *mc_get_stream(mc_engine *e);
 double mc_avg_runtime_ms(const mc_engine *e);      /* mean ms per mc_process call after 10 warm-ups */
 int mc_enable_kernel_timing(mc_engine *e, int on); /* HIP events around the MAC kernel */

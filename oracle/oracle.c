@@ -500,7 +500,8 @@ void orc_upols_set_shard(orc_upols *u, size_t pb, size_t pe) {
 }
 
 /* first half of a block: everything up to this shard's share of the wet block
- * (pre-predelay), SURVEY Appendix B / §8(e) */
+ * (pre-predelay), SURVEY Appendix B / §8(e).  This model assumes constant select
+ * and predelay (Appendix B); live changes are checked against orc_ref_*. */
 void orc_upols_partial(orc_upols *u, const float *in1, const float *in2, double *wetL, double *wetR) {
     up_grow(u);
     size_t t = u->t;

@@ -771,3 +771,173 @@ def test_longer_jack_periods(oracle_mod, gpu_lib, period, pd, taps):
     with pytest.raises(McError):
         c.onProcess(x[0, :256], x[1, :256])  # wrong period length
     c.close()
+
+
+def _run_with_predelay_events(oracle_mod, n_ref, nb, taps, events, mode, period=256, compat=True, p_extra=None, max_batch=None):
+    """events: {call index: predelay}.  mode 'jack' = one period per mc_process call, 'batch' = mc_process_batch
+    calls cut at the events.  Returns (got, want)."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    pm = period // 256
+    ncalls = nb // pm
+    x = make_input(nb * 256)
+    irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05)]
+    p0 = dict(BASE, wet=0.7, panWet=0.25, **(p_extra or {}))
+    p1 = dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True) if compat else None
+    c = _conv(fftSize=n_ref, max_batch=max_batch or (pm if mode == "jack" else 16 * pm), period=period, compat=compat)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+        if ref:
+            ref.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    if ref:
+        apply_params(ref, p0, p1, True)
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    q = 0
+    while q < ncalls:
+        if q in events:
+            c.cc[0].value.predelay = events[q]
+            if ref:
+                ref.set(0, predelay=events[q])
+        n = 1
+        if mode == "batch":
+            nxt = min([e for e in events if e > q] + [ncalls])
+            n = min(16, nxt - q)
+        s = slice(q * period, (q + n) * period)
+        if ref:
+            want[:, s] = ref.process(x[0, s], x[1, s], block=period)
+        if mode == "jack":
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        q += n
+    c.close()
+    return x, irs, (p0, p1), got, want
+
+
+@pytest.mark.parametrize("mode", ["jack", "batch"])
+@pytest.mark.parametrize("period", [256, 512])
+def test_predelay_change_keeps_old_blocks_at_their_offset(oracle_mod, gpu_lib, mode, period):
+    """A predelay CC while audio runs.  The reference shifts each call's contribution by the predelay current at
+    that call (conv.cu:411-415): blocks already played ring out at the old offset.  Up, down, back to zero, and
+    two changes closer together than the IR length."""
+    nb, n_ref = 120, 8192
+    pm = period // 256
+    events = {0: 300, 20 // pm: 1500, 50 // pm: 64, 58 // pm: 0, 90 // pm: 4096}
+    _, _, _, got, want = _run_with_predelay_events(oracle_mod, n_ref, nb, (5000, 4000), events, mode, period)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+@pytest.mark.parametrize("mode", ["jack", "batch"])
+def test_predelay_change_in_the_tail_drop_regime(oracle_mod, gpu_lib, mode):
+    """Predelay changes with taps + 255 + predelay > N_ref (Q8 active before and after; the shipped defaults)."""
+    nb, n_ref = 100, 4096
+    events = {0: 1024, 30: 2000, 55: 1024, 75: 0}
+    _, _, _, got, want = _run_with_predelay_events(oracle_mod, n_ref, nb, (3072, 3072), events, mode)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+def test_predelay_knob_sweep(oracle_mod, gpu_lib):
+    """A controller sweep: a new predelay on every period for 40 periods (handleCC steps of 64 frames)."""
+    nb, n_ref = 110, 8192
+    events = {10 + k: 64 * (k + 1) for k in range(40)}
+    events.update({70 + k: 64 * (40 - 3 * k) for k in range(12)})
+    _, _, _, got, want = _run_with_predelay_events(oracle_mod, n_ref, nb, (6000, 5000), events, "jack", p_extra=dict(vsteps=7))
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+def test_predelay_change_linear_mode_and_streaming_flush(oracle_mod, gpu_lib):
+    """compat = 0 (plain linear convolution): output = sum over epochs of conv(input of the epoch) delayed by the
+    epoch's predelay.  max_batch 4 makes the retirement run the streaming MAC in many chunks."""
+    nb, n_ref = 64, 8192
+    events = {0: 100, 25: 2000, 40: 7}
+    x, irs, (p0, p1), got, _ = _run_with_predelay_events(oracle_mod, n_ref, nb, (5000, 4000), events, "jack", compat=False,
+                                                        max_batch=4)
+    # direct model in float64: settled gains only after the cold-start ramp, so build it from per-block gains
+    n = nb * 256
+    edges = sorted(events) + [nb]
+    want = np.zeros((2, n + 16384))
+    e = [0.0, 0.0]
+    for b in range(nb):
+        pd = [events[k] for k in sorted(events) if k <= b][-1]
+        for half, (p, ir) in enumerate(((p0, irs[0]), (p1, irs[1]))):
+            v = p["vsteps"] if b == 0 else max(p["vsteps"] - b, 0)
+            e[half] += (p["wet"] - e[half]) / (v + 5)
+            pw = p["panWet"]
+            gl = (1 - pw if pw >= 0 else 1) * p["level"] * e[half]
+            gr = (1 + pw if pw <= 0 else 1) * p["level"] * e[half]
+            xb = x[half, b * 256:(b + 1) * 256].astype(np.float64)
+            yl = np.convolve(xb, ir[:, 0].astype(np.float64))
+            yr = np.convolve(xb, ir[:, 1].astype(np.float64))
+            o = b * 256 + pd
+            want[0, o:o + len(yl)] += gl * yl
+            want[1, o:o + len(yr)] += gr * yr
+    want = np.clip(want[:, :n], -1, 1)
+    for half, p in enumerate((p0, p1)):
+        pdry = p["panDry"]
+        want[0] += x[half] * p["dry"] * (1 - pdry if pdry >= 0 else 1) * p["level"]
+        want[1] += x[half] * p["dry"] * (1 + pdry if pdry <= 0 else 1) * p["level"]
+    assert edges[0] == 0
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+def test_predelay_change_sharded(oracle_mod, gpu_lib):
+    """Three virtual shards: every shard retires its own partition share; the sum of the partials still equals
+    the reference after predelay changes (the partial carries the predelay and the retired tails)."""
+    import torch
+
+    from cuda_audio_amd.sharded import partitions_for, shard_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref, T = 96, 16384, 8
+    x = make_input(nb * 256)
+    irs = [make_ir(12000, seed=11, norm=0.05), make_ir(9000, seed=22, norm=0.05)]
+    P = partitions_for(12000, n_ref)
+    world = 3
+    p0, p1 = dict(BASE, predelay=500, wet=0.7), dict(BASE, select=1)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    shards = []
+    for r in range(world):
+        pb, pe = shard_bounds(P, world, r)
+        s = _conv(fftSize=n_ref, max_batch=T, part_begin=pb, part_end=pe)
+        s.use_torch_stream()
+        shards.append(s)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        for s in shards:
+            s.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    for s in shards:
+        apply_params(s, p0, p1, False)
+    events = {24: 3000, 56: 0, 64: 1024}
+    dx = torch.from_numpy(x).cuda()
+    out = torch.zeros(2, nb * 256, device="cuda")
+    want = np.zeros((2, nb * 256))
+    parts = [torch.zeros(2 * T * 256, device="cuda") for _ in range(world)]
+    for b in range(0, nb, T):
+        if b in events:
+            ref.set(0, predelay=events[b])
+            for s in shards:
+                s.cc[0].value.predelay = events[b]
+        sl = slice(b * 256, (b + T) * 256)
+        want[:, sl] = ref.process(x[0, sl], x[1, sl])
+        xin = dx[:, sl].contiguous()
+        for s, p in zip(shards, parts):
+            s.partial_device(xin[0].data_ptr(), xin[1].data_ptr(), p.data_ptr(), T)
+        total = parts[0] + parts[1] + parts[2]
+        o = torch.zeros(2, T * 256, device="cuda")
+        shards[0].finish_device(xin[0].data_ptr(), xin[1].data_ptr(), total.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
+        for s in shards[1:]:
+            s.finish_device(None, None, None, None, None, T)
+        out[:, sl] = o
+    torch.cuda.synchronize()
+    err = rms(out.cpu().numpy() - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    for s in shards:
+        s.close()
