@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
                                              float4* __restrict__ sums,      // [T] raw {S1,S2,A1,A2} or null
                                              float4* __restrict__ slotgain,  // [MC_MAXV][ring] or null
                                              const float2* __restrict__ g_tw,
-                                             uint2* __restrict__ fdl16 = nullptr) {  // fp16 mirror of the delay line or null
+                                             uint2* __restrict__ fdl16,  // fp16 mirror of the delay line or null
+                                             float* __restrict__ xhist, int xr,  // [2][xr] input history ring or null
+                                             float4* __restrict__ gring, int rc,  // [MC_MAXV][rc] gains of past blocks
+                                             int64_t tabs0) {                     // absolute block of t = 0
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
@@ -100,6 +103,11 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
             for (int r = 0; r < 4; r++) {  // n = lane + 64 r < 256: the block; 256..511 stay zero
                 int64_t f = (int64_t)t * MC_B + lane + 64 * r;
                 if (f < n_frames) v[r] = make_float2(in1[f * in_stride], in2[f * in_stride]);
+                if (xhist) {  // input history for the Q8 pass of later calls
+                    const int64_t tau = tabs0 * MC_B + f;
+                    xhist[(size_t)(tau & (xr - 1))] = v[r].x;
+                    xhist[(size_t)xr + (tau & (xr - 1))] = v[r].y;
+                }
             }
         }
         fft512_wave<-1>(v, lds, s_tw, lane);
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
             if (slotgain && lane < MC_MAXV) {
                 const float* gv = ptab[(int64_t)t * pstride].g[lane];
                 slotgain[(size_t)lane * ring + ((slot0 + t) & (ring - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                if (gring) gring[(size_t)lane * rc + (size_t)((tabs0 + t) & (rc - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
             }
         }
         __syncthreads();  // lds reused by the next transform
@@ -560,11 +569,11 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
     }
 }
 
-// Wet sample (t, m) of the current batch: the overlap-add of this block's first
-// half with the previous block's second half, straight from the segment ring.
-__device__ __forceinline__ float2 batch_wet(const float* __restrict__ seg, int sr, int seg0, int t, int m) {
-    const float* cur = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
-    const float* prv = seg + (size_t)((seg0 + t + sr - 1) & (sr - 1)) * 2 * FFT_N;
+// Wet sample m of absolute block b: the overlap-add of that block's first half with
+// the previous block's second half, straight from the segment ring (slot = block mod sr).
+__device__ __forceinline__ float2 batch_wet(const float* __restrict__ seg, int sr, int64_t b, int m) {
+    const float* cur = seg + (size_t)(b & (sr - 1)) * 2 * FFT_N;
+    const float* prv = seg + (size_t)((b + sr - 1) & (sr - 1)) * 2 * FFT_N;
     return make_float2(cur[m] + prv[MC_B + m], cur[FFT_N + m] + prv[FFT_N + MC_B + m]);
 }
 
@@ -591,20 +600,17 @@ __device__ __forceinline__ float2 retired_at(const float* __restrict__ ring, int
 }
 
 // Wet sample of this engine delayed by the live predelay: writes the thread's own
-// overlap-added sample to the wet ring (history for later batches / periods) and
-// returns sample tau - predelay (from this batch's segments when it is that young).
-__device__ __forceinline__ float2 delayed_wet(const float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet, int wr,
-                                              int T, int t, int m, int64_t tau0, int64_t predelay) {
-    const int64_t i = (int64_t)t * MC_B + m;
-    const int64_t tau = tau0 + i;
+// overlap-added sample (absolute sample tau) to the wet ring (history for later batches /
+// periods) and returns sample tau - predelay: from the segment ring when it is no older than
+// win0, the first sample whose segments this call has computed, else from the wet ring.
+__device__ __forceinline__ float2 delayed_wet(const float* __restrict__ seg, int sr, float* __restrict__ wet, int wr, int64_t tau,
+                                              int64_t win0, int64_t predelay) {
     const int64_t u = tau - predelay;
-    const float2 own = batch_wet(seg, sr, seg0, t, m);
+    const float2 own = batch_wet(seg, sr, tau >> 8, (int)(tau & 255));
     wet[(size_t)(tau & (wr - 1))] = own.x;
     wet[(size_t)wr + (tau & (wr - 1))] = own.y;
-    if (u >= tau0) {  // delayed sample lies in this batch: not in the ring yet
-        const int64_t j = u - tau0;
-        return (j == i) ? own : batch_wet(seg, sr, seg0, (int)(j >> 8), (int)(j & 255));
-    }
+    if (u == tau) return own;
+    if (u >= win0) return batch_wet(seg, sr, u >> 8, (int)(u & 255));
     if (u >= 0) return make_float2(wet[(size_t)(u & (wr - 1))], wet[(size_t)wr + (u & (wr - 1))]);
     return make_float2(0.f, 0.f);
 }
@@ -615,11 +621,11 @@ __device__ __forceinline__ float2 delayed_wet(const float* __restrict__ seg, int
 // buffer [2][T*256] that goes into the cross-GPU sum.  (A single engine needs
 // no such pass: k_post does the same straight from the segment ring.)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int seg0, int T, float* __restrict__ wet, int wr,
+__global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int sr, int T, float* __restrict__ wet, int wr,
                                              int64_t tabs0, int64_t predelay, Retired ret, float* __restrict__ lin) {
     const int t = blockIdx.x, m = threadIdx.x;
     const int64_t tau = (tabs0 + t) * MC_B + m;
-    float2 w = delayed_wet(seg, sr, seg0, wet, wr, T, t, m, tabs0 * MC_B, predelay);
+    float2 w = delayed_wet(seg, sr, wet, wr, tau, tabs0 * MC_B, predelay);
     if (tau < ret.end) {
         const float2 r = retired_at(ret.mac, ret.rr, tau);
         w.x += r.x;
@@ -796,15 +802,20 @@ __device__ __forceinline__ void write_history(const TailDrop& td, int64_t tau, i
 // mix (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
 // conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, int seg0, const float* __restrict__ lin,
+__global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
                                               float* __restrict__ wet, int wr, const double* __restrict__ cring, int rc,
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
-                                              int64_t predelay, int64_t n_ref, int compat, TailDrop td, int pm, Retired ret) {
+                                              int first, int64_t win0, int64_t predelay, int64_t n_ref, int compat, TailDrop td,
+                                              int pm, Retired ret) {
+    // T blocks in the batch starting at absolute block tabs0; this launch finishes blocks first .. first + gridDim.x - 1
+    // of it (the whole batch unless the engine runs block-sliced) into outL/outR, which start at block `first`.
+    // win0: first absolute sample whose segments this call has computed.
     // pm = blocks per reference call (JACK period / 256): Q1/Q2/Q8 windows are measured from the call start
-    const int t = blockIdx.x, m = threadIdx.x;
+    const int t = first + blockIdx.x, m = threadIdx.x;
     const int64_t i = (int64_t)t * MC_B + m;
+    const int64_t o = (int64_t)blockIdx.x * MC_B + m;
     const int64_t tau0 = tabs0 * MC_B;
     const int64_t tau = tau0 + i;
     const int64_t u = tau - predelay;
@@ -813,7 +824,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
         wl = lin[i];
         wr_ = lin[(size_t)T * MC_B + i];
     } else {
-        const float2 w = delayed_wet(seg, sr, seg0, wet, wr, T, t, m, tau0, predelay);
+        const float2 w = delayed_wet(seg, sr, wet, wr, tau, win0, predelay);
         wl = w.x;
         wr_ = w.y;
         if (tau < ret.end) {
@@ -852,8 +863,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     }
     const BlockParams& bp = ptab[(int64_t)t * pstride];
     const float x1 = in1[i], x2 = in2[i];
-    write_history(td, tau, tabs0 + t, m, x1, x2, bp, rc);
-    if (td.on) {
+    if (td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
         float dl, dr;
         tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
         wl -= dl;
@@ -861,8 +871,8 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     }
     float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
     float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
-    outL[i] = vl + x1 * bp.d[0] + x2 * bp.d[1];
-    outR[i] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+    outL[o] = vl + x1 * bp.d[0] + x2 * bp.d[1];
+    outR[o] = vr + x1 * bp.d[2] + x2 * bp.d[3];
 }
 
 // ---------------------------------------------------------------------------
@@ -875,10 +885,10 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
 // Q1/Q2 window terms of the old blocks for future output samples, minus their
 // Q8 drops.  Both accumulate: tails of earlier epochs may still be pending.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flush_ola(const float* __restrict__ seg, int sr, int seg0, int T, int64_t tabs0,
+__global__ __launch_bounds__(256) void k_flush_ola(const float* __restrict__ seg, int sr, int64_t tabs0,
                                                    int64_t predelay_old, float* __restrict__ res, int rr, int64_t end) {
     const int t = blockIdx.x, m = threadIdx.x;
-    const float2 w = batch_wet(seg, sr, seg0, t, m);
+    const float2 w = batch_wet(seg, sr, tabs0 + t, m);
     const int64_t tau = (tabs0 + t) * MC_B + m + predelay_old;
     if (tau < end) {
         res[(size_t)(tau & (rr - 1))] += w.x;

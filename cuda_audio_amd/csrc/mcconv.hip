@@ -139,6 +139,8 @@ struct mc_engine {
         VoiceSums vs;
         int vir[2][MC_MAXV];  // IR index per half and voice (-1 = none)
         int slot = 0;
+        int first = 0, count = 0;  // output blocks this engine finishes (the whole batch unless block-sliced)
+        uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
     } pipe[2];
     int pipe_head = 0, pipe_count = 0;
     uint64_t batch_seq = 0;
@@ -148,6 +150,7 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
+    bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     bool uniform_valid[2] = {false, false};
     BlockParams uniform_bp[2];
 
@@ -202,6 +205,7 @@ int zero_state(mc_engine* e) {
     HIP_TRY(hipMemsetAsync(e->d_res_fix, 0, sizeof(float) * 2 * (size_t)e->rr, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->res_end = e->epoch_b0 = e->cur_delay = 0;
+    e->sliced = false;
     for (int i = 0; i < 2; i++)
         for (int v = 0; v < MC_MAXV; v++) e->voice[i][v] = mc_engine::VoiceSlot();
     for (int v = 0; v < MC_MAXV; v++) {
@@ -589,6 +593,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay) {
         return MC_OK;
     }
     if (e->pipe_count) return fail(MC_ERR_STATE, "predelay changed while a batch awaits mc_finish_batch_device");
+    if (e->sliced) return fail(MC_ERR_STATE, "predelay changed on a block-sliced engine (mc_reset first)");
     const uint64_t b0 = e->t_front, bs = e->epoch_b0, d_old = e->cur_delay;
     // the latest old call started at block b0 - pm; the reference cuts its contribution n_ref samples later
     const uint64_t new_end = (b0 - (uint64_t)e->pm) * MC_B + e->cfg.n_ref;
@@ -615,13 +620,14 @@ int retire_epoch(mc_engine* e, uint64_t new_delay) {
         // silent blocks into the delay line (n_frames = 0: the inputs are never read)
         hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
-                           (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16);
+                           (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
+                           (int64_t)0);
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
         hipLaunchKernelGGL(k_inv, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
                            mo.sc, Tc, e->d_seg, e->sr, seg0, e->d_tw);
-        hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, Tc, (int64_t)tv, (int64_t)d_old,
+        hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, (int64_t)tv, (int64_t)d_old,
                            e->d_res_mac, e->rr, (int64_t)new_end);
         tv += (uint64_t)Tc;
         F -= Tc;
@@ -645,11 +651,20 @@ int retire_epoch(mc_engine* e, uint64_t new_delay) {
     return MC_OK;
 }
 
-// forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial
-int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin) {
+// forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial.
+// first/count: the output blocks of the batch this engine will finish (block-sliced operation when count < T):
+// everything that later calls depend on (delay line, gains, Q1/Q2 sums, histories) is still produced for all T
+// blocks, the partition sums and inverse transforms only for the slice and the few blocks before it that the
+// overlap-add and the predelay reach back to.
+int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin, int first, int count) {
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
     if (e->pipe_count >= kPipe) return fail(MC_ERR_STATE, "%d batches already await mc_finish_batch_device", kPipe);
     if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
+    const bool slice = !(first == 0 && count == T);
+    if (first < 0 || count <= 0 || first + count > T) return fail(MC_ERR_ARG, "slice [%d, %d) outside the batch of %d", first, first + count, T);
+    if (slice && lin) return fail(MC_ERR_ARG, "a partition shard cannot be block-sliced");
+    if (slice && e->res_end > e->t_front * MC_B) return fail(MC_ERR_STATE, "block-sliced call while a retired predelay epoch is ringing out");
+    if (!slice && e->sliced) return fail(MC_ERR_STATE, "whole-batch call on a block-sliced engine (mc_reset first)");
     Staged st;
     {
         mc_cc_value cc[2];
@@ -658,6 +673,19 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         if (!rc) rc = stage_params(e, T, cc, &st);
         if (rc) return rc;
     }
+    // window of blocks to run the MAC / inverse over: the slice plus what the predelay and the overlap-add reach back to
+    int halo = 0;
+    if (slice) {
+        halo = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
+        halo = (int)std::min<uint64_t>((uint64_t)halo, e->t_front + (uint64_t)first);  // the stream starts at block 0
+        if (count + halo > e->Tmax) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds max_batch %d", count, halo, e->Tmax);
+        e->sliced = true;
+    }
+    const uint64_t wblock = e->t_front + (uint64_t)first - (uint64_t)halo;  // first block of the window (absolute)
+    const int Tw = count + halo;
+    st.ctx.first = first;
+    st.ctx.count = count;
+    st.ctx.win0 = wblock * MC_B;
     e->pipe[(e->pipe_head + e->pipe_count) % kPipe] = st.ctx;
     e->spec_valid = false;
     BlockParams* d_ptab = st.d_ptab;
@@ -665,11 +693,11 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     const int pstride = st.ctx.pstride;
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
-    const int seg0 = (int)(e->t_front & (uint64_t)(e->sr - 1));
 
-    // K1
+    // K1: all T blocks
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
-                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16);
+                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
+                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front);
     hipEvent_t *k0 = nullptr, *k1 = nullptr;
     if (e->ktiming) {
         if (e->kev_n == kEvPool) {
@@ -678,12 +706,17 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         }
         k0 = &e->kev[e->kev_n][0];
         k1 = &e->kev[e->kev_n][1];
-        e->kev_blocks[e->kev_n] = (uint32_t)T;
+        e->kev_blocks[e->kev_n] = (uint32_t)Tw;
         HIP_TRY(hipEventRecord(*k0, e->stream));
     }
     MacOut mo;
     {
-        int rc = launch_mac_batch(e, st.act, st.nact, pstride != 0, T, slot0, &mo);
+        // a window that starts before this batch sees the previous batch's gains too
+        bool per_slot = pstride != 0;
+        if (slice)
+            for (int a = 0; a < st.nact; a++)
+                if (e->gain_change_block[st.act[a].v] + (uint64_t)st.act[a].p_end + (uint64_t)halo > e->t_front) per_slot = true;
+        int rc = launch_mac_batch(e, st.act, st.nact, per_slot, Tw, (int)(wblock & (uint64_t)(e->ring - 1)), &mo);
         if (rc) return rc;
     }
     if (e->ktiming) {
@@ -694,10 +727,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     }
 
     // K3 (+ K4 for shards)
-    hipLaunchKernelGGL(k_inv, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum, mo.sc, T,
-                       e->d_seg, e->sr, seg0, e->d_tw);
+    hipLaunchKernelGGL(k_inv, dim3((Tw + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum, mo.sc, Tw,
+                       e->d_seg, e->sr, (int)(wblock & (uint64_t)(e->sr - 1)), e->d_tw);
     if (lin)
-        hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, seg0, T, e->d_wet, e->wr, (int64_t)e->t_front,
+        hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, T, e->d_wet, e->wr, (int64_t)e->t_front,
                            (int64_t)st.ctx.predelay, make_retired(e), lin);
     HIP_TRY(hipGetLastError());
     e->pipe_count++;
@@ -724,9 +757,9 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
                            1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot);
         hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
                            e->d_ctot);
-        hipLaunchKernelGGL(k_post, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, (int)(ctx.t0 & (uint64_t)(e->sr - 1)), lin_sum,
-                           e->d_wet, e->wr, e->d_cring, e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T,
-                           (int64_t)ctx.t0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
+        hipLaunchKernelGGL(k_post, dim3(ctx.count), dim3(256), 0, e->stream, e->d_seg, e->sr, lin_sum, e->d_wet, e->wr, e->d_cring,
+                           e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first,
+                           (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
                            make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e));
         HIP_TRY(hipGetLastError());
     }
@@ -740,6 +773,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
 int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
+    if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
     const size_t cap = (size_t)e->Tmax * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
@@ -878,7 +912,7 @@ int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, 
     std::memcpy(e->h_io + 1 * cap, in2, bytes);
     HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_io[1], e->h_io + 1 * cap, bytes, hipMemcpyHostToDevice, e->stream));
-    int rc = run_front(e, e->d_io[0], e->d_io[1], T, nullptr);
+    int rc = run_front(e, e->d_io[0], e->d_io[1], T, nullptr, 0, T);
     if (rc) return rc;
     rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], T);
     if (rc) return rc;
@@ -945,8 +979,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->Tmax = (int)cfg->max_batch;
     e->Pcap = cfg->max_partitions ? (int)cfg->max_partitions : (int)((cfg->n_ref - 1024 + MC_B - 1) / MC_B);
     e->Pstride = (int)next_pow2((uint64_t)round_up(e->Pcap, 16));
-    e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tmax + 16);
-    e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels
+    e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tmax + 64);  // + reach-back of a block slice (<= 33)
+    e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels; a slice + reach-back <= Tmax
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
     e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
@@ -1109,7 +1143,8 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (er == hipSuccess) er = hipMemsetAsync(ir.d_H, 0, sizeof(float4) * (size_t)MC_NB * e->Pstride, e->stream);
     if (er == hipSuccess) {
         hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
-                           ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw);
+                           ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0);
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
@@ -1226,7 +1261,18 @@ int mc_process_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
     if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
-    int rc = run_front(e, d_in1, d_in2, T, nullptr);
+    int rc = run_front(e, d_in1, d_in2, T, nullptr, 0, T);
+    if (rc) return rc;
+    return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
+}
+
+int mc_process_batch_slice_device(mc_engine* e, const float* d_in1, const float* d_in2, float* d_outL, float* d_outR,
+                                  uint64_t nblocks, uint64_t first, uint64_t count) {
+    if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (first > (uint64_t)T || count > (uint64_t)T) return fail(MC_ERR_ARG, "slice outside the batch");
+    int rc = run_front(e, d_in1, d_in2, T, nullptr, (int)first, (int)count);
     if (rc) return rc;
     return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
 }
@@ -1235,7 +1281,7 @@ int mc_partial_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
     if (!e || !d_in1 || !d_in2 || !d_partial) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
-    return run_front(e, d_in1, d_in2, T, d_partial);
+    return run_front(e, d_in1, d_in2, T, d_partial, 0, T);
 }
 
 int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, const float* d_wet_sum, float* d_outL,

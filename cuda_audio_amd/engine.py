@@ -168,6 +168,11 @@ class Convolution:
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous."""
         check(self._L.mc_process_batch_device(self._h, d_in1, d_in2, d_outL, d_outR, nblocks))
 
+    def process_slice_device(self, d_in1, d_in2, d_outL, d_outR, nblocks, first, count):
+        """Block-sliced operation: the same batch on every GPU, this engine finishes output blocks
+        [first, first + count) into d_outL / d_outR (count * 256 floats each); asynchronous."""
+        check(self._L.mc_process_batch_slice_device(self._h, d_in1, d_in2, d_outL, d_outR, nblocks, first, count))
+
     def partial_device(self, d_in1, d_in2, d_partial, nblocks):
         check(self._L.mc_partial_batch_device(self._h, d_in1, d_in2, d_partial, nblocks))
 

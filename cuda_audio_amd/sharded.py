@@ -37,6 +37,52 @@ def shard_bounds(n_partitions, world, rank):
     return pb, pe
 
 
+def slice_bounds(nblocks, world, rank, multiple=1):
+    """Output blocks [first, first + count) of a batch that `rank` finishes in block-sliced operation:
+    contiguous, `multiple`-aligned (the JACK period in blocks), covering the batch exactly once."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    units = nblocks // multiple
+    if units * multiple != nblocks or units < world:
+        raise ValueError("batch of %d blocks does not split over %d ranks in multiples of %d" % (nblocks, world, multiple))
+    lo = rank * units // world
+    hi = (rank + 1) * units // world
+    return lo * multiple, (hi - lo) * multiple
+
+
+class BlockSlicedConvolution:
+    """Throughput scaling without a data-path collective: every rank holds the whole IR set and is fed the same
+    batch; rank r finishes its slice of the output blocks (mc_process_batch_slice_device).  `gather=True` collects
+    the slices on every rank (all_gather) so that `out` is the full [2, n] result, as a single engine would give."""
+
+    def __init__(self, conv, world=1, rank=0, group=None, period_blocks=1):
+        self.conv, self.world, self.rank, self.group, self.pm = conv, world, rank, group, period_blocks
+        conv.use_torch_stream()
+
+    def process(self, x, out, gather=True):
+        n = x.shape[1]
+        if n % BLOCK:
+            raise ValueError("length must be a multiple of 256")
+        T = n // BLOCK
+        first, count = slice_bounds(T, self.world, self.rank, self.pm)
+        mine = torch.empty(2, count * BLOCK, dtype=torch.float32, device=x.device)
+        self.conv.process_slice_device(x[0].data_ptr(), x[1].data_ptr(), mine[0].data_ptr(), mine[1].data_ptr(), T, first, count)
+        if self.world == 1:
+            out.copy_(mine)
+            return out
+        if not gather:
+            out[:, first * BLOCK:(first + count) * BLOCK] = mine
+            return out
+        import torch.distributed as dist
+
+        for r in range(self.world):  # slices may differ in length: one broadcast per owner
+            f, c = slice_bounds(T, self.world, r, self.pm)
+            buf = mine if r == self.rank else torch.empty(2, c * BLOCK, dtype=torch.float32, device=x.device)
+            dist.broadcast(buf, src=r, group=self.group)
+            out[:, f * BLOCK:(f + c) * BLOCK] = buf
+        return out
+
+
 class HipShard:
     """One rank's engine: cuda_audio_amd.Convolution restricted to its partition range."""
 

@@ -124,6 +124,16 @@ int mc_process_batch(mc_engine *e, const float *in1, const float *in2, float *ou
 /* the same with device-resident buffers; asynchronous on the engine's stream */
 int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
                             uint64_t nblocks);
+/* Block-sliced operation - scaling batch throughput over GPUs without a data-path collective.  The output blocks
+ * of a batch are independent given the input, so G engines (one per GPU) are fed the SAME batch and each finishes
+ * `count` output blocks starting at block `first` of it into d_outL/d_outR (count*256 floats each).  Every engine
+ * still transforms all nblocks inputs (its delay line, gains, Q1/Q2 sums and histories stay complete: ~2% of the
+ * work); the partition sums and inverse transforms run only over the slice plus the <= 33 blocks before it that the
+ * overlap-add and the predelay reach back to (count + reach-back <= max_batch).  An engine that has been called
+ * with a proper slice keeps no wet history outside its slices: until mc_reset it accepts only sliced calls, and a
+ * predelay change is refused (MC_ERR_STATE).  first = 0, count = nblocks is mc_process_batch_device. */
+int mc_process_batch_slice_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
+                                  uint64_t nblocks, uint64_t first, uint64_t count);
 /* Sharded operation: d_partial receives this engine's share of the wet signal,
  * 2*nblocks*256 floats ([L | R], overlap-added and already shifted by the predelay);
  * after the caller has summed the partials of all shards (RCCL reduce / all-reduce),

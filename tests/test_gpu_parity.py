@@ -941,3 +941,71 @@ def test_predelay_change_sharded(oracle_mod, gpu_lib):
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("n_ref,taps,pd,period", [(8192, (5000, 4000), 0, 256), (8192, (5000, 4000), 700, 256),
+                                                  (4096, (3072, 3072), 1024, 256), (8192, (6000, 4000), 300, 512),
+                                                  (16384, (9000, 15000), 8192, 256)],
+                         ids=["pd0", "pd700", "pd1024_taildrop", "period512", "max_predelay"])
+def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, pd, period):
+    """Block-sliced operation (throughput scaling without a collective): three engines are fed the same batches and
+    each finishes its slice of the output blocks.  The concatenation equals the reference - through the cold-start
+    ramp (per-slot gains), an IR switch with cross-fade and a wet change, for slices that start inside the batch."""
+    import torch
+
+    from cuda_audio_amd._lib import McError
+    from cuda_audio_amd.sharded import slice_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    pm = period // 256
+    world, T, nbat = 3, 48, 5
+    nb = T * nbat
+    x = make_input(nb * 256)
+    irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05), make_ir(taps[0] - 500, seed=33, norm=0.05)]
+    p0 = dict(BASE, predelay=pd, wet=0.7, panWet=0.25, speed=20)
+    p1 = dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    # slice + reach-back (predelay / 256 + 1 blocks) must fit max_batch
+    engines = [_conv(fftSize=n_ref, max_batch=T + 16, period=period) for _ in range(world)]
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        for c in engines:
+            c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    for c in engines:
+        apply_params(c, p0, p1, False)
+        c.use_torch_stream()
+    dx = torch.from_numpy(x).cuda()
+    out = torch.zeros(2, nb * 256, device="cuda")
+    want = np.zeros((2, nb * 256))
+    for k in range(nbat):
+        if k == 2:  # select CC on half 0 (cross-fade over `speed` calls) and a wet change on half 1
+            ref.set(0, select=2, vsteps=20)
+            ref.set(1, wet=0.3)
+            for c in engines:
+                c.cc[0].value.update(select=2, vsteps=20)
+                c.cc[1].value.wet = 0.3
+        sl = slice(k * T * 256, (k + 1) * T * 256)
+        want[:, sl] = ref.process(x[0, sl], x[1, sl], block=period)
+        xin = dx[:, sl].contiguous()
+        for r, c in enumerate(engines):
+            first, count = slice_bounds(T, world, r, pm)
+            o = torch.zeros(2, count * 256, device="cuda")
+            c.process_slice_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T, first, count)
+            out[:, (k * T + first) * 256:(k * T + first + count) * 256] = o
+    torch.cuda.synchronize()
+    err = rms(out.cpu().numpy() - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    # a sliced engine refuses whole-batch and single-period calls and predelay changes until it is reset
+    c = engines[1]
+    xin = dx[:, : T * 256].contiguous()
+    o = torch.zeros(2, T * 256, device="cuda")
+    with pytest.raises(McError):
+        c.process_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
+    c.cc[0].value.predelay = (pd + 64) % 8192
+    with pytest.raises(McError):
+        c.process_slice_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T, 0, T // 3)
+    c.reset()
+    c.process_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
+    for c in engines:
+        c.close()
