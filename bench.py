@@ -49,8 +49,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-block-per-call (JACK) measurement")
+    ap.add_argument("--shard", choices=["blocks", "partitions"], default="blocks",
+                    help="N > 1. blocks: every GPU is fed the same batch and finishes its slice of the output blocks - no "
+                         "data-path collective, the slices are gathered to rank 0 (default: batch throughput). partitions: "
+                         "every GPU holds 1/N of the IR partitions and the partial wet blocks are summed with RCCL (the "
+                         "layout that also shortens a single real-time period)")
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
-                    help="N > 1: sum of partial wet blocks to rank 0 (default) or to every rank")
+                    help="--shard partitions: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
@@ -150,8 +155,15 @@ def main():
     # shard bounds: multiples of 16 partitions
     from cuda_audio_amd.sharded import shard_bounds
 
+    from cuda_audio_amd.sharded import slice_bounds
+
     shard_world = world if world > 1 else (a.emulate_world if a.force_sharded and a.emulate_world > 1 else 1)
-    if shard_world > 1:
+    by_blocks = sharded and a.shard == "blocks"
+    if by_blocks:
+        # weak scaling: every rank finishes --blocks output blocks of a batch of N x --blocks
+        T = a.blocks * shard_world
+    first, count = slice_bounds(T, shard_world, rank) if by_blocks else (0, T)
+    if shard_world > 1 and not by_blocks:
         pb, pe = shard_bounds(P, shard_world, rank)
     else:
         pb, pe = 0, 0
@@ -159,8 +171,8 @@ def main():
         a.mode = "stream"
     thr = (T + 1) if a.mode == "stream" else 0
     eng = Convolution("bench", a.fft_size, max_batch=T, device=local, part_begin=pb,
-                      part_end=pe if shard_world > 1 else 0, stream_threshold=min(thr, 16385), precision=a.precision)
-    if shard_world > 1 and pe == pb:
+                      part_end=pe if (shard_world > 1 and not by_blocks) else 0, stream_threshold=min(thr, 16385), precision=a.precision)
+    if shard_world > 1 and not by_blocks and pe == pb:
         raise SystemExit("empty shard; use fewer ranks")
     # two distinct IRs (seed 5678 + path): in1 -> (L,R) through IR 0, in2 -> (L,R) through IR 1,
     # i.e. four different convolution paths, so the 4-path byte count has no shared spectra
@@ -174,7 +186,11 @@ def main():
     xs = make_input(n_distinct * T * BLOCK, seed=1234)
     d_in = torch.from_numpy(xs).to(dev)
     d_out = torch.zeros(2, T * BLOCK, device=dev)
-    d_parts = [torch.zeros(2 * T * BLOCK, device=dev) for _ in range(2)] if sharded else None
+    d_parts = [torch.zeros(2 * T * BLOCK, device=dev) for _ in range(2)] if (sharded and not by_blocks) else None
+    # block slices: this rank's output blocks of a batch (double-buffered), gathered on rank 0
+    d_slices = [torch.zeros(2, count * BLOCK, device=dev) for _ in range(2)] if by_blocks else None
+    d_gather = ([[torch.zeros(2, count * BLOCK, device=dev) for _ in range(world)] for _ in range(2)]
+                if by_blocks and rank == 0 and world > 1 else None)
     # one compute stream for the engine, the torch ops and (as the stream the collectives order themselves
     # against) RCCL: partial -> reduce -> finish are then ordered by the streams, not by host synchronisation
     torch.cuda.synchronize()
@@ -197,11 +213,46 @@ def main():
         else:
             eng.finish_device(None, None, None, None, None, T)
 
+    class _Done:
+        def wait(self):
+            pass
+
+    def gather_slices(sl, k):
+        # the only exchange of the block-sliced layout: count * 2 KB per rank and batch to rank 0, off the data path
+        if world == 1:
+            return _Done()
+        if a.backend == "gloo":  # rehearsal: through host memory
+            h = sl.cpu()
+            hl = [torch.zeros_like(h) for _ in range(world)] if rank == 0 else None
+            dist.gather(h, hl, dst=0)
+            if rank == 0:
+                for g, t in zip(d_gather[k % 2], hl):
+                    g.copy_(t)
+            return _Done()
+        return dist.gather(sl, d_gather[k % 2] if rank == 0 else None, dst=0, async_op=True)
+
+    def retire_slices():
+        work, k = pending.pop(0)
+        work.wait()
+        if kept is not None and rank == 0:
+            kept.append(torch.cat(d_gather[k % 2], dim=1) if world > 1 else d_slices[k % 2].clone())
+
     def step(k):
         o = (k % n_distinct) * T * BLOCK
         i1, i2 = d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr()
         if not sharded:
             eng.process_device(i1, i2, d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+            return
+        if by_blocks:
+            sl = d_slices[k % 2]
+            eng.process_slice_device(i1, i2, sl[0].data_ptr(), sl[1].data_ptr(), T, first, count)
+            work = gather_slices(sl, k)
+            # the gather of batch k overlaps the MAC of batch k+1: batch k-1 is complete on rank 0 now
+            if pending and not a.no_overlap:
+                retire_slices()
+            pending.append((work, k))
+            if a.no_overlap:
+                retire_slices()
             return
         part = d_parts[k % 2]
         eng.partial_device(i1, i2, part.data_ptr(), T)
@@ -218,7 +269,7 @@ def main():
 
     def drain():
         while pending:
-            retire()
+            retire_slices() if by_blocks else retire()
 
     # settle the cold-start cross-fade (Q7) so the timed region is steady state
     for k in range(max(a.warmup, 1)):
@@ -331,9 +382,10 @@ def main():
                 o = (k % n_distinct) * T * BLOCK
                 full.process_device(d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr(), ref_out[0].data_ptr(), ref_out[1].data_ptr(), T)
                 torch.cuda.synchronize()
-                num += float(((kept[k] - ref_out).double() ** 2).sum())
-                den += float((ref_out.double() ** 2).sum())
-            n_el = nchk * ref_out.numel()
+                want = ref_out if kept[k].shape == ref_out.shape else ref_out[:, first * BLOCK:(first + count) * BLOCK]
+                num += float(((kept[k] - want).double() ** 2).sum())
+                den += float((want.double() ** 2).sum())
+            n_el = nchk * kept[0].numel()
             sharded_check = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
             full.close()
         kept = None
@@ -358,7 +410,7 @@ def main():
         "note": "SURVEY 8(d) accounting: every block re-reads 4 IR paths + 2 delay-line inputs; bytes x blocks / MAC kernel time",
     }
     common = {"kernel": "k_mac_resident" if ks["resident"] else "k_mac_stream", "traffic": traffic,
-              "kernel_avg_ms": round(kern_avg_ms, 5), "kernel_launches": ks["launches"], "blocks_per_launch": T,
+              "kernel_avg_ms": round(kern_avg_ms, 5), "kernel_launches": ks["launches"], "blocks_per_launch": (ks["blocks"] // max(ks["launches"], 1)) if ks["launches"] else T,
               "flops_per_block": int(flops_per_block)}
     if ks["resident"]:
         # the batch kernel keeps the IR on chip across the blocks of a launch (HBM traffic << algorithmic bytes):
@@ -388,7 +440,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if by_blocks else "strong",
             "vs_baseline": None,
             "dtype": "f32" if a.precision == "fp32" else "f16 storage, f32 accumulate",
             "data": "synthetic",
@@ -400,8 +452,12 @@ def main():
                 "paths": 4,
                 "mode": a.mode,
                 "parallelism": "single GPU" if not sharded else
-                f"IR partitions sharded over {world} GPU(s) + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} {a.collective} of partial wet blocks"
-                f"{'' if a.no_overlap else ', overlapped with the next batch'}",
+                (f"output blocks of every batch sliced over {world} GPU(s) ({count} blocks each, every GPU holds the whole IR "
+                 f"and transforms the whole input); no data-path collective, slices gathered to rank 0 "
+                 f"({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})" if by_blocks else
+                 f"IR partitions sharded over {world} GPU(s) + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} {a.collective} of partial wet blocks")
+                + ("" if a.no_overlap else ", overlapped with the next batch"),
+                "shard": (a.shard if sharded else None),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -692,14 +692,26 @@ __global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(const float4* __restr
 
 __global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restrict__ cring, int rc, int64_t tabs0,
                                                          const double* __restrict__ ctot) {
-    const int t = blockIdx.x * CORR_CHUNK + threadIdx.x;
-    double base[4] = {0, 0, 0, 0};
+    __shared__ double s_red[CORR_CHUNK][4];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * CORR_CHUNK + tid;
+    // totals of the chunks before this one: strided partial sums, then a tree in LDS (long batches have hundreds)
+    double part[4] = {0, 0, 0, 0};
+    for (int k = tid; k < (int)blockIdx.x; k += CORR_CHUNK)
+        for (int c = 0; c < 4; c++) part[c] += ctot[k * 4 + c];
+    for (int c = 0; c < 4; c++) s_red[tid][c] = part[c];
+    __syncthreads();
+    for (int off = CORR_CHUNK / 2; off > 0; off >>= 1) {
+        if (tid < off)
+            for (int c = 0; c < 4; c++) s_red[tid][c] += s_red[tid + off][c];
+        __syncthreads();
+    }
+    double base[4];
+    for (int c = 0; c < 4; c++) base[c] = s_red[0][c];
     if (tabs0 > 0) {
         const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
-        for (int c = 0; c < 4; c++) base[c] = p[c];
+        for (int c = 0; c < 4; c++) base[c] += p[c];
     }
-    for (int k = 0; k < (int)blockIdx.x; k++)  // wave-uniform addresses: broadcast loads
-        for (int c = 0; c < 4; c++) base[c] += ctot[k * 4 + c];
     if (t < T) {
         double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) o[c] += base[c];

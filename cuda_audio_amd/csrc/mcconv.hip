@@ -96,7 +96,8 @@ struct mc_engine {
     BlockParams* d_ptab = nullptr;
     float2* d_tw = nullptr;
     float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // in1, in2, outL, outR staging for host-pointer calls
-    float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Tmax * 256
+    int Thost = 0;                                          // longest batch through host buffers (staging capacity)
+    float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Thost * 256
     float* hd_io = nullptr;                                 // device-side address of h_io (mapped, zero-copy)
     unsigned* h_flag = nullptr;                             // completion word of the single-period path (mapped)
     unsigned* hd_flag = nullptr;
@@ -258,6 +259,30 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
     for (int t = 0; t < T; t++) {
         const uint64_t blk = e->t_front + (uint64_t)t;
         BlockParams& bp = tab[t];
+        if (t == 1) {
+            // steady state (every cross-fade coefficient has reached its target): the remaining blocks of the batch
+            // repeat block 0 - one table entry serves all, whatever the batch length
+            bool settled = true;
+            for (int i = 0; i < 2; i++) {
+                const int sv = voice_slot_for(e, i, (int)cc[i].select, blk);
+                for (int v = 0; v < MC_MAXV; v++) {
+                    const mc_engine::VoiceSlot& s = e->voice[i][v];
+                    if (s.ir >= 0 && s.coef != ((v == sv) ? (double)cc[i].wet : 0.0)) settled = false;
+                }
+            }
+            if (settled) {
+                const uint64_t last = e->t_front + (uint64_t)T - 1;
+                for (int v = 0; v < MC_MAXV; v++) {
+                    const float* g = tab[0].g[v];
+                    if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f || g[3] != 0.f) {
+                        e->last_nz_voice[v] = last;
+                        for (int i = 0; i < 2; i++)
+                            if (g[0 * 2 + i] != 0.f || g[1 * 2 + i] != 0.f) e->voice[i][v].last_nz = last;
+                    }
+                }
+                break;
+            }
+        }
         std::memset(&bp, 0, sizeof(bp));
         // the reference advances its live spectra once per onProcess call: with periods of 512 / 1024 frames the
         // 2 / 4 internal blocks of a call share the call's coefficients
@@ -682,7 +707,6 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         e->sliced = true;
     }
     const uint64_t wblock = e->t_front + (uint64_t)first - (uint64_t)halo;  // first block of the window (absolute)
-    const int Tw = count + halo;
     st.ctx.first = first;
     st.ctx.count = count;
     st.ctx.win0 = wblock * MC_B;
@@ -698,37 +722,41 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
                        e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front);
-    hipEvent_t *k0 = nullptr, *k1 = nullptr;
-    if (e->ktiming) {
-        if (e->kev_n == kEvPool) {
-            int rc = drain_kernel_events(e);
-            if (rc) return rc;
-        }
-        k0 = &e->kev[e->kev_n][0];
-        k1 = &e->kev[e->kev_n][1];
-        e->kev_blocks[e->kev_n] = (uint32_t)Tw;
-        HIP_TRY(hipEventRecord(*k0, e->stream));
+    if (e->ktiming && e->kev_n == kEvPool) {
+        int rc = drain_kernel_events(e);
+        if (rc) return rc;
     }
-    MacOut mo;
     {
         // a window that starts before this batch sees the previous batch's gains too
         bool per_slot = pstride != 0;
         if (slice)
             for (int a = 0; a < st.nact; a++)
                 if (e->gain_change_block[st.act[a].v] + (uint64_t)st.act[a].p_end + (uint64_t)halo > e->t_front) per_slot = true;
-        int rc = launch_mac_batch(e, st.act, st.nact, per_slot, Tw, (int)(wblock & (uint64_t)(e->ring - 1)), &mo);
-        if (rc) return rc;
+        // K2 + K3.  The reach-back blocks run as their own short launch (for <= 33 blocks the streaming kernel), so
+        // that the slice itself fills whole 256-block tiles of the resident kernel.
+        const int parts[2][2] = {{0, halo}, {halo, count}};
+        for (int h = 0; h < 2; h++) {
+            const int off = parts[h][0], n = parts[h][1];
+            if (n <= 0) continue;
+            const uint64_t b = wblock + (uint64_t)off;
+            const bool timed = e->ktiming && h == 1;  // the MAC of the blocks this engine finishes: the roofline kernel
+            if (timed) {
+                e->kev_blocks[e->kev_n] = (uint32_t)n;
+                HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
+            }
+            MacOut mo;
+            int rc = launch_mac_batch(e, st.act, st.nact, per_slot, n, (int)(b & (uint64_t)(e->ring - 1)), &mo);
+            if (rc) return rc;
+            if (timed) {
+                HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
+                e->kev_n++;
+                e->ks.resident = mo.resident ? 1 : 0;
+                e->ks.partitions = (uint32_t)mo.swept;
+            }
+            hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
+                               mo.sc, n, e->d_seg, e->sr, (int)(b & (uint64_t)(e->sr - 1)), e->d_tw);
+        }
     }
-    if (e->ktiming) {
-        HIP_TRY(hipEventRecord(*k1, e->stream));
-        e->kev_n++;
-        e->ks.resident = mo.resident ? 1 : 0;
-        e->ks.partitions = (uint32_t)mo.swept;
-    }
-
-    // K3 (+ K4 for shards)
-    hipLaunchKernelGGL(k_inv, dim3((Tw + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum, mo.sc, Tw,
-                       e->d_seg, e->sr, (int)(wblock & (uint64_t)(e->sr - 1)), e->d_tw);
     if (lin)
         hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, T, e->d_wet, e->wr, (int64_t)e->t_front,
                            (int64_t)st.ctx.predelay, make_retired(e), lin);
@@ -774,7 +802,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
-    const size_t cap = (size_t)e->Tmax * MC_B;
+    const size_t cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
     Staged st;
@@ -905,9 +933,9 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
 
 int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
-    if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
+    if (T <= 0 || T > e->Thost) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d] (host-buffer batches)", T, e->Thost);
     const size_t n = (size_t)T * MC_B, bytes = n * sizeof(float);
-    const size_t cap = (size_t)e->Tmax * MC_B;
+    const size_t cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, bytes);
     std::memcpy(e->h_io + 1 * cap, in2, bytes);
     HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
@@ -959,7 +987,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (cfg->struct_size != sizeof(mc_config)) return fail(MC_ERR_ARG, "mc_config size mismatch (%u vs %zu)", cfg->struct_size, sizeof(mc_config));
     if (cfg->n_ref < 4096 || (cfg->n_ref & (cfg->n_ref - 1))) return fail(MC_ERR_ARG, "n_ref must be a power of two >= 4096");
     if (cfg->n_ref > (1ull << 26)) return fail(MC_ERR_ARG, "n_ref too large");
-    if (cfg->max_batch < 1 || cfg->max_batch > 16384) return fail(MC_ERR_ARG, "max_batch must be in [1, 16384]");
+    if (cfg->max_batch < 1 || cfg->max_batch > 131072) return fail(MC_ERR_ARG, "max_batch must be in [1, 131072]");
     if ((cfg->part_begin % 16) || (cfg->part_end % 16)) return fail(MC_ERR_ARG, "partition shard bounds must be multiples of 16");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1032,8 +1060,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
     ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
-    for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Tmax * MC_B));
-    ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Tmax * MC_B, hipHostMallocMapped));
+    e->Thost = std::min(e->Tmax, 16384);  // host-buffer calls stage through pinned memory: bounded
+    for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Thost * MC_B));
+    ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
     ENG_TRY(hipHostMalloc(&e->h_flag, 64, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));

@@ -156,7 +156,7 @@ class Convolution:
         if n % MC_BLOCK or in2.shape[0] != n:
             raise ValueError("inputs must have equal length, a multiple of 256")
         out = np.empty((2, n), np.float32)
-        step = self.max_batch * MC_BLOCK
+        step = min(self.max_batch, 16384) * MC_BLOCK  # host-buffer batches stage through pinned memory: <= 16384 blocks
         for o in range(0, n, step):
             m = min(step, n - o)
             a, b = in1[o : o + m], in2[o : o + m]

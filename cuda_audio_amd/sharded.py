@@ -50,14 +50,37 @@ def slice_bounds(nblocks, world, rank, multiple=1):
     return lo * multiple, (hi - lo) * multiple
 
 
+class HipSlicer:
+    """One rank's engine for block-sliced operation: the whole IR set, launches ordered with torch's stream."""
+
+    def __init__(self, fft_size, max_batch, device, compat=True, period=256):
+        from .engine import Convolution
+
+        self.conv = Convolution("slicer", fft_size, max_batch=max_batch, device=device, compat=compat, period=period)
+        self.conv.use_torch_stream()
+
+    def prepare(self, idx, lr, nframes=1024):
+        self.conv.prepare(idx, lr, nframes)
+
+    def set_params(self, half, **kw):
+        self.conv.cc[half].value.update(**kw)
+
+    def process_slice(self, x, mine, nblocks, first, count):
+        self.conv.process_slice_device(x[0].data_ptr(), x[1].data_ptr(), mine[0].data_ptr(), mine[1].data_ptr(), nblocks, first, count)
+
+    def close(self):
+        self.conv.close()
+
+
 class BlockSlicedConvolution:
     """Throughput scaling without a data-path collective: every rank holds the whole IR set and is fed the same
-    batch; rank r finishes its slice of the output blocks (mc_process_batch_slice_device).  `gather=True` collects
-    the slices on every rank (all_gather) so that `out` is the full [2, n] result, as a single engine would give."""
+    batch; rank r finishes its slice of the output blocks (mc_process_batch_slice_device).  `slicer` is a HipSlicer
+    (product) or any object with the same process_slice interface (the gloo CPU tests inject an oracle-backed one).
+    `gather=True` collects the slices on every rank so that `out` is the full [2, n] result, as a single engine
+    would give; otherwise only this rank's slice of `out` is written."""
 
-    def __init__(self, conv, world=1, rank=0, group=None, period_blocks=1):
-        self.conv, self.world, self.rank, self.group, self.pm = conv, world, rank, group, period_blocks
-        conv.use_torch_stream()
+    def __init__(self, slicer, world=1, rank=0, group=None, period_blocks=1):
+        self.slicer, self.world, self.rank, self.group, self.pm = slicer, world, rank, group, period_blocks
 
     def process(self, x, out, gather=True):
         n = x.shape[1]
@@ -65,19 +88,16 @@ class BlockSlicedConvolution:
             raise ValueError("length must be a multiple of 256")
         T = n // BLOCK
         first, count = slice_bounds(T, self.world, self.rank, self.pm)
-        mine = torch.empty(2, count * BLOCK, dtype=torch.float32, device=x.device)
-        self.conv.process_slice_device(x[0].data_ptr(), x[1].data_ptr(), mine[0].data_ptr(), mine[1].data_ptr(), T, first, count)
-        if self.world == 1:
-            out.copy_(mine)
-            return out
-        if not gather:
-            out[:, first * BLOCK:(first + count) * BLOCK] = mine
+        mine = torch.empty(2, count * BLOCK, dtype=out.dtype, device=x.device)
+        self.slicer.process_slice(x, mine, T, first, count)
+        out[:, first * BLOCK:(first + count) * BLOCK] = mine
+        if self.world == 1 or not gather:
             return out
         import torch.distributed as dist
 
         for r in range(self.world):  # slices may differ in length: one broadcast per owner
             f, c = slice_bounds(T, self.world, r, self.pm)
-            buf = mine if r == self.rank else torch.empty(2, c * BLOCK, dtype=torch.float32, device=x.device)
+            buf = mine if r == self.rank else torch.empty(2, c * BLOCK, dtype=out.dtype, device=x.device)
             dist.broadcast(buf, src=r, group=self.group)
             out[:, f * BLOCK:(f + c) * BLOCK] = buf
         return out

@@ -75,3 +75,54 @@ def test_two_ranks_share_one_card_sum_of_partials_matches_oracle():
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["sig"] > 1e-3
     assert ret["err"] <= RMS_TOL, ret["err"]
+
+
+def _slice_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from cuda_audio_amd.sharded import BlockSlicedConvolution, HipSlicer
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nb, n_ref, T = 96, 32768, 32
+        x = make_input(nb * 256)
+        irs = [make_ir(20000, seed=3, norm=0.05), make_ir(15000, seed=4, norm=0.05)]
+        sl = HipSlicer(n_ref, T, 0)
+        for i, ir in enumerate(irs):
+            sl.prepare(i, ir)
+        sl.set_params(1, select=1)
+        sl.set_params(0, predelay=300, panWet=-0.25)
+        drv = BlockSlicedConvolution(sl, world=world, rank=rank)
+        dx = torch.from_numpy(x).cuda()
+        out = torch.zeros(2, nb * 256, device="cuda")
+        for b in range(0, nb, T):
+            s = slice(b * 256, (b + T) * 256)
+            drv.process(dx[:, s].contiguous(), out[:, s])
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        import oracle
+
+        ref = oracle.RefCompat(n_ref, True)
+        for i, ir in enumerate(irs):
+            ref.prepare(i, ir)
+        ref.set(1, select=1)
+        ref.set(0, predelay=300, panWet=-0.25)
+        want = ref.process(x[0], x[1])
+        ret[rank] = float(np.sqrt(np.mean((got - want) ** 2)))
+        sl.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_block_slices_gathered_on_every_rank():
+    """Block-sliced operation with two processes on one card: each finishes half of the output blocks of every
+    batch; after the gather both hold the reference's output."""
+    import oracle
+
+    oracle.lib()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slice_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] <= RMS_TOL and ret[1] <= RMS_TOL, dict(ret)

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cuda_audio_amd.sharded import ShardedConvolution, partitions_for, shard_bounds
+from cuda_audio_amd.sharded import BlockSlicedConvolution, ShardedConvolution, partitions_for, shard_bounds, slice_bounds
 
 
 def test_shard_bounds_tile_the_range():
@@ -99,3 +99,71 @@ def test_two_rank_gloo_sum_of_partials_equals_unsharded():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret["sig"] > 1e-3
     assert ret["err"] < 1e-14, ret["err"]
+
+
+def test_slice_bounds_tile_the_batch():
+    for T in (8, 48, 8192, 65536):
+        for world in (1, 2, 3, 4, 8):
+            for pm in (1, 2, 4):
+                if T % pm or T // pm < world:
+                    continue
+                got = [slice_bounds(T, world, r, pm) for r in range(world)]
+                assert got[0][0] == 0 and sum(c for _, c in got) == T
+                pos = 0
+                for f, c in got:
+                    assert f == pos and c > 0 and f % pm == 0 and c % pm == 0
+                    pos += c
+    with pytest.raises(ValueError):
+        slice_bounds(6, 4, 0, 2)
+
+
+class OracleSlicer:
+    """Test double with HipSlicer's interface: runs the whole batch through the float64 restatement (every rank
+    sees the whole input, as the product does) and hands back the requested slice."""
+
+    def __init__(self, n_ref, ir):
+        import oracle
+
+        self.o = oracle.RefCompat(n_ref, True)
+        self.o.prepare(0, ir)
+
+    def process_slice(self, x, mine, nblocks, first, count):
+        xn = x.numpy()
+        full = self.o.process(xn[0], xn[1])
+        mine.numpy()[:] = full[:, first * 256:(first + count) * 256]
+
+
+def _slice_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_audio_amd.synth import make_input, make_ir
+
+        nbat, T, n_ref = 3, 10, 4096
+        x = make_input(nbat * T * 256)
+        ir = make_ir(2500, seed=3, norm=0.05)
+        drv = BlockSlicedConvolution(OracleSlicer(n_ref, ir), world=world, rank=rank)
+        out = torch.zeros(2, nbat * T * 256, dtype=torch.float64)
+        for k in range(nbat):
+            sl = slice(k * T * 256, (k + 1) * T * 256)
+            drv.process(torch.from_numpy(x[:, sl].copy()), out[:, sl])
+        import oracle
+
+        full = oracle.RefCompat(n_ref, True)
+        full.prepare(0, ir)
+        want = full.process(x[0], x[1])
+        ret[rank] = float(np.sqrt(np.mean((out.numpy() - want) ** 2)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_block_slices_gather_to_the_full_output():
+    import oracle
+
+    oracle.lib()
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slice_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0] < 1e-15 and ret[1] < 1e-15
