@@ -190,7 +190,7 @@ def main():
     # block slices: this rank's output blocks of a batch (double-buffered), gathered on rank 0
     d_slices = [torch.zeros(2, count * BLOCK, device=dev) for _ in range(2)] if by_blocks else None
     d_gather = ([[torch.zeros(2, count * BLOCK, device=dev) for _ in range(world)] for _ in range(2)]
-                if by_blocks and rank == 0 and world > 1 else None)
+                if by_blocks and rank == 0 and shard_world == world else None)
     # one compute stream for the engine, the torch ops and (as the stream the collectives order themselves
     # against) RCCL: partial -> reduce -> finish are then ordered by the streams, not by host synchronisation
     torch.cuda.synchronize()
@@ -219,7 +219,7 @@ def main():
 
     def gather_slices(sl, k):
         # the only exchange of the block-sliced layout: count * 2 KB per rank and batch to rank 0, off the data path
-        if world == 1:
+        if shard_world != world:  # one emulated rank of several: nothing to gather
             return _Done()
         if a.backend == "gloo":  # rehearsal: through host memory
             h = sl.cpu()
@@ -235,7 +235,7 @@ def main():
         work, k = pending.pop(0)
         work.wait()
         if kept is not None and rank == 0:
-            kept.append(torch.cat(d_gather[k % 2], dim=1) if world > 1 else d_slices[k % 2].clone())
+            kept.append(torch.cat(d_gather[k % 2], dim=1) if d_gather is not None else d_slices[k % 2].clone())
 
     def step(k):
         o = (k % n_distinct) * T * BLOCK
