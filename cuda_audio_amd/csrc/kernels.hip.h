@@ -993,10 +993,71 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
     __shared__ float4 s_sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const BlockParams& bp = ptab[0];  // read through global memory: a local copy indexed at run time would live in scratch
-    load_twiddles(s_tw, g_tw);
-    s_in[0][tid] = in1[tid];
-    s_in[1][tid] = in2[tid];
+    const int m = tid;
+    const int64_t tau0 = tabs0 * MC_B, tau = tau0 + m, u = tau - predelay;
+
+    // ---- every load whose address is known now is issued here, in one round of memory latency: the period
+    // (PCIe), twiddles, this bin's chunk partials and partition-0 spectra, the previous tail, the delayed wet
+    // samples, the Q1/Q2 prefix entries and the retired-epoch residuals.  (The kernel is one workgroup on the
+    // critical path of a JACK period: six dependent round trips cost more than everything it computes.)
+    const float xin1 = in1[tid], xin2 = in2[tid];
+    const float2 tw0 = g_tw[tid], tw1 = g_tw[tid + 256];
+    float4 ysum = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float4* src = part + (size_t)tid * nsum;
+        for (int c = 0; c < nsum; c++) {
+            const float4 a = src[c];
+            ysum.x += a.x;
+            ysum.y += a.y;
+            ysum.z += a.z;
+            ysum.w += a.w;
+        }
+    }
+    float4 h0v[MC_MAXV], h1v[MC_MAXV];
+#pragma unroll
+    for (int vi = 0; vi < MC_MAXV; vi++) {  // constant indices: runtime-indexed kernel-argument arrays go to scratch
+        h0v[vi] = h1v[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vi < vset.n) {
+            h0v[vi] = vset.H0[vi][(size_t)tid * pstride_ir];
+            h1v[vi] = vset.H1[vi][(size_t)tid * pstride_ir];
+        }
+    }
+    const float* prv = seg + (size_t)((seg0 + sr - 1) & (sr - 1)) * 2 * FFT_N;
+    const float prvL = prv[MC_B + m], prvR = prv[FFT_N + MC_B + m];
+    float dwl = 0.f, dwr = 0.f;  // delayed wet sample when it predates this period
+    if (u >= 0 && u < tau0) {
+        dwl = wet[(size_t)(u & (wr - 1))];
+        dwr = wet[(size_t)wr + (u & (wr - 1))];
+    }
+    float2 ra = make_float2(0.f, 0.f), rb = ra;
+    if (tau < ret.end) {  // what blocks played under an earlier predelay still owe
+        ra = retired_at(ret.mac, ret.rr, tau);
+        rb = retired_at(ret.fix, ret.rr, tau);
+    }
+    const int64_t thi = u >> 8;
+    int64_t tlo = tau - n_ref >= 0 ? ((tau - n_ref) >> 8) : -1;
+    if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
+    const bool corr_on = compat && u >= 0 && thi > tlo;
+    double ca[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, cprev[4] = {0, 0, 0, 0};
+    if (corr_on && thi != tabs0) {
+        const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) ca[c] = pa[c];
+    }
+    if (corr_on && tlo >= 0) {
+        const double* pb = cring + (size_t)(tlo & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) cb[c] = pb[c];
+    }
+    if (tid == 64 && tabs0 > 0) {  // the thread that will extend the prefix sums
+        const double* pp = cring + (size_t)((tabs0 + rc - 1) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) cprev[c] = pp[c];
+    }
+
+    s_tw[tid] = tw0;
+    s_tw[tid + 256] = tw1;
+    s_in[0][tid] = xin1;
+    s_in[1][tid] = xin2;
     __syncthreads();
+    float4 xs_keep[4];  // wave 0: the block's spectra, stored to the delay line at the end of the kernel
     if (wave == 0) {
         float2 v[8];
 #pragma unroll
@@ -1020,35 +1081,19 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             }
             const float4 xs = make_float4(x1.x, x1.y, x2.x, x2.y);
             s_x[k] = xs;
-            fdl[(size_t)k * ring + slot0] = xs;
-            if (fdl16) fdl16[(size_t)k * ring + slot0] = pack_half4(xs, FDL16_SCALE);
-        }
-        if (lane < MC_MAXV)
-            slotgain[(size_t)lane * ring + slot0] = make_float4(bp.g[lane][0], bp.g[lane][1], bp.g[lane][2], bp.g[lane][3]);
-    } else {
-        for (int k = tid - 64; k < MC_NB; k += 192) {
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4* src = part + (size_t)k * nsum;
-            for (int c = 0; c < nsum; c++) {
-                const float4 a = src[c];
-                y.x += a.x;
-                y.y += a.y;
-                y.z += a.z;
-                y.w += a.w;
-            }
-            s_y[k] = y;
+            xs_keep[j] = xs;
         }
     }
     __syncthreads();
-    if (vset.n > 0) {  // partition 0 of every voice's IRs against the new block
+    {  // bin tid: chunk partials (partitions >= 1) + partition 0 of every voice's IRs against the new block
         const int k = tid;
         const float4 x = s_x[k];
-        float4 y = s_y[k];
+        float4 y = ysum;
 #pragma unroll
-        for (int vi = 0; vi < MC_MAXV; vi++) {  // constant indices: runtime-indexed kernel-argument arrays go to scratch
+        for (int vi = 0; vi < MC_MAXV; vi++) {
             if (vi >= vset.n) break;
             const float* g = ptab->g[vset.vid[vi]];
-            const float4 h0 = vset.H0[vi][(size_t)k * pstride_ir], h1 = vset.H1[vi][(size_t)k * pstride_ir];
+            const float4 h0 = h0v[vi], h1 = h1v[vi];
             float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
             if (k == 0) {
                 cmac<true>(a0, h0.x, h0.y, x.x, x.y);
@@ -1091,85 +1136,50 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             v[r] = w;
         }
         fft512_wave<+1, false>(v, s_fft, s_tw, lane);
+    } else if (tid == 64) {
+        // meanwhile: this block's Q1/Q2 terms and the new prefix entry (float64, serial)
+        double d[4] = {0, 0, 0, 0};
+        if (compat) corr_terms(s_sa, bp, vs, inv_n, d);
+        for (int c = 0; c < 4; c++) s_c[c] = cprev[c] + d[c];
     }
     __syncthreads();
+    // No global store is issued before the output has left: a barrier drains the vector-memory counter, so every
+    // store ahead of it would put its acknowledgement latency on the critical path.
+    float seg_lo[2], seg_hi[2], own_wet[2];
     {
         // overlap-add with the previous block's tail; this block's segments go to the ring
-        const int m = tid;
         const float sc = 1.0f / FFT_N;
         const float2 lo = s_fft[m], hi = s_fft[MC_B + m];
-        float* cur = seg + (size_t)seg0 * 2 * FFT_N;
-        const float* prv = seg + (size_t)((seg0 + sr - 1) & (sr - 1)) * 2 * FFT_N;
-        const float wl = lo.x * sc + prv[MC_B + m], wr_ = lo.y * sc + prv[FFT_N + MC_B + m];
-        cur[m] = lo.x * sc;
-        cur[MC_B + m] = hi.x * sc;
-        cur[FFT_N + m] = lo.y * sc;
-        cur[FFT_N + MC_B + m] = hi.y * sc;
-        const int64_t tau = tabs0 * MC_B + m;
-        wet[(size_t)(tau & (wr - 1))] = wl;
-        wet[(size_t)wr + (tau & (wr - 1))] = wr_;
-        s_wet[0][m] = wl;
-        s_wet[1][m] = wr_;
-        if (m == 0) {
-            double d[4] = {0, 0, 0, 0};
-            if (compat) corr_terms(s_sa, bp, vs, inv_n, d);
-            const double* pb = cring + (size_t)((tabs0 + rc - 1) & (rc - 1)) * 4;
-            double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
-            for (int c = 0; c < 4; c++) {
-                const double vv = (tabs0 > 0 ? pb[c] : 0.0) + d[c];
-                o[c] = vv;
-                s_c[c] = vv;
-            }
-        }
+        seg_lo[0] = lo.x * sc;
+        seg_lo[1] = lo.y * sc;
+        seg_hi[0] = hi.x * sc;
+        seg_hi[1] = hi.y * sc;
+        own_wet[0] = seg_lo[0] + prvL;
+        own_wet[1] = seg_lo[1] + prvR;
+        s_wet[0][m] = own_wet[0];
+        s_wet[1][m] = own_wet[1];
     }
     __syncthreads();
     {
-        const int m = tid;
-        const int64_t tau = tabs0 * MC_B + m;
-        const int64_t u = tau - predelay;
-        float wl = 0.f, wr_ = 0.f;
-        if (u >= 0) {
-            if (u >= tabs0 * MC_B) {  // inside this block: not yet visible through global memory
-                wl = s_wet[0][u - tabs0 * MC_B];
-                wr_ = s_wet[1][u - tabs0 * MC_B];
-            } else {
-                wl = wet[(size_t)(u & (wr - 1))];
-                wr_ = wet[(size_t)wr + (u & (wr - 1))];
-            }
+        float wl = dwl, wr_ = dwr;
+        if (u >= tau0) {  // inside this block: not yet visible through global memory
+            wl = s_wet[0][u - tau0];
+            wr_ = s_wet[1][u - tau0];
         }
-        if (tau < ret.end) {  // what blocks played under an earlier predelay still owe
-            const float2 ra = retired_at(ret.mac, ret.rr, tau), rb = retired_at(ret.fix, ret.rr, tau);
-            wl += ra.x + rb.x;
-            wr_ += ra.y + rb.y;
-        }
+        wl += ra.x + rb.x;
+        wr_ += ra.y + rb.y;
         double cl = 0.0, cr = 0.0;
-        if (compat && u >= 0) {
-            const int64_t thi = u >> 8;
-            const int64_t vv = tau - n_ref;
-            int64_t tlo = vv >= 0 ? (vv >> 8) : -1;
-            if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
-            if (thi > tlo) {
-                double a[4];
-                if (thi == tabs0) {
-                    for (int c = 0; c < 4; c++) a[c] = s_c[c];
-                } else {
-                    const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
-                    for (int c = 0; c < 4; c++) a[c] = pa[c];
-                }
-                if (tlo >= 0) {
-                    const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
-                    for (int c = 0; c < 4; c++) a[c] -= b[c];
-                }
-                const double sg = (u & 1) ? -1.0 : 1.0;
-                cl = a[0] + sg * a[2];
-                cr = a[1] + sg * a[3];
-            }
+        if (corr_on) {
+            if (thi == tabs0)
+                for (int c = 0; c < 4; c++) ca[c] = s_c[c];
+            const double sg = (u & 1) ? -1.0 : 1.0;
+            cl = (ca[0] - cb[0]) + sg * (ca[2] - cb[2]);
+            cr = (ca[1] - cb[1]) + sg * (ca[3] - cb[3]);
         }
-        const float x1 = s_in[0][m], x2 = s_in[1][m];
-        write_history(td, tau, tabs0, m, x1, x2, bp, rc);
+        const float x1 = xin1, x2 = xin2;
         if (td.on) {
             float dl, dr;
-            tail_drop(td, tau, tabs0 * MC_B, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, 1, ret.b0, INT64_MAX);
+            tail_drop(td, tau, tau0, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, 1, ret.b0, INT64_MAX);
             wl -= dl;
             wr_ -= dr;
         }
@@ -1177,6 +1187,31 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
         outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
         outR[m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+        write_history(td, tau, tabs0, m, x1, x2, bp, rc);
+    }
+    // the state later periods need: delay-line slot, slot gains, segments, wet ring, Q1/Q2 prefix entry
+    {
+        float* cur = seg + (size_t)seg0 * 2 * FFT_N;
+        cur[m] = seg_lo[0];
+        cur[MC_B + m] = seg_hi[0];
+        cur[FFT_N + m] = seg_lo[1];
+        cur[FFT_N + MC_B + m] = seg_hi[1];
+        wet[(size_t)(tau & (wr - 1))] = own_wet[0];
+        wet[(size_t)wr + (tau & (wr - 1))] = own_wet[1];
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = lane + 64 * j;
+                fdl[(size_t)k * ring + slot0] = xs_keep[j];
+                if (fdl16) fdl16[(size_t)k * ring + slot0] = pack_half4(xs_keep[j], FDL16_SCALE);
+            }
+            if (lane < MC_MAXV)
+                slotgain[(size_t)lane * ring + slot0] = make_float4(bp.g[lane][0], bp.g[lane][1], bp.g[lane][2], bp.g[lane][3]);
+        }
+        if (m == 0) {
+            double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
+            for (int c = 0; c < 4; c++) o[c] = s_c[c];
+        }
     }
     // publish completion to the host (mapped pinned memory): all waves drain their stores at the barrier
     // (__syncthreads waits vmcnt(0)), then ONE lane issues the system-scope release and the sequence number
