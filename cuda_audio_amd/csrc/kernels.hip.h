@@ -667,11 +667,16 @@ __global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(const float4* __restr
                                                            int pstride, int T, VoiceSums vs, double inv_n, int compat,
                                                            double* __restrict__ cring, int rc, int64_t tabs0,
                                                            double* __restrict__ ctot) {
+    // T <= CORR_CHUNK (one workgroup): the base of the previous batch is added here and k_corr_fix is not run
     __shared__ double s_part[CORR_CHUNK][4];
     const int tid = threadIdx.x;
     const int t = blockIdx.x * CORR_CHUNK + tid;
     double d[4] = {0, 0, 0, 0};
     if (t < T && compat) corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
+    if (T <= CORR_CHUNK && tid == 0 && tabs0 > 0) {
+        const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) d[c] += p[c];
+    }
     for (int c = 0; c < 4; c++) s_part[tid][c] = d[c];
     __syncthreads();
     for (int off = 1; off < CORR_CHUNK; off <<= 1) {  // inclusive Hillis-Steele scan
@@ -820,7 +825,10 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
                                               int first, int64_t win0, int64_t predelay, int64_t n_ref, int compat, TailDrop td,
-                                              int pm, Retired ret) {
+                                              int pm, Retired ret, unsigned* __restrict__ done_flag, unsigned seq,
+                                              unsigned* __restrict__ done_ctr) {
+    // done_flag (mapped host memory) != null: outL/outR are host buffers and the last workgroup to finish
+    // publishes `seq` once every workgroup's output is visible to the host (one JACK period of 512 / 1024 frames)
     // T blocks in the batch starting at absolute block tabs0; this launch finishes blocks first .. first + gridDim.x - 1
     // of it (the whole batch unless the engine runs block-sliced) into outL/outR, which start at block `first`.
     // win0: first absolute sample whose segments this call has computed.
@@ -885,6 +893,17 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
     outL[o] = vl + x1 * bp.d[0] + x2 * bp.d[1];
     outR[o] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+    if (done_flag) {
+        __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
+        if (m == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this workgroup's output is on the host
+            const unsigned old = atomicAdd(done_ctr, 1u);
+            if (old == gridDim.x - 1) {
+                *done_ctr = 0;
+                __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

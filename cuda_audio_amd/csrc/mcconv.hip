@@ -102,6 +102,7 @@ struct mc_engine {
     unsigned* h_flag = nullptr;                             // completion word of the single-period path (mapped)
     unsigned* hd_flag = nullptr;
     unsigned flag_seq = 0;
+    unsigned* d_done_ctr = nullptr;  // workgroups of the period's last kernel that have finished
     bool spin_wait = true;
     BlockParams* h_ptab[kStageBufs] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ptab_ev[kStageBufs];
@@ -770,7 +771,8 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 // Q1/Q2 prefix sums, predelay, clamp, dry mix of the oldest batch in flight.
 // d_outL == null: the caller does not need this engine's output (a non-root
 // rank of a reduce-to-root): nothing is launched, the batch is just retired.
-int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* lin_sum, float* d_outL, float* d_outR, int T) {
+int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* lin_sum, float* d_outL, float* d_outR, int T,
+             bool publish = false) {  // publish: the buffers are mapped host memory; raise the completion flag
     if (!e->pipe_count) return fail(MC_ERR_STATE, "no batch awaits its second half");
     const mc_engine::BatchCtx ctx = e->pipe[e->pipe_head];
     if (ctx.T != T) return fail(MC_ERR_ARG, "finish of %d blocks but the pending batch has %d", T, ctx.T);
@@ -783,15 +785,38 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
         hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
                            1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot);
-        hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
-                           e->d_ctot);
+        if (nchunks > 1)  // a single chunk adds its base itself
+            hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
+                               e->d_ctot);
         hipLaunchKernelGGL(k_post, dim3(ctx.count), dim3(256), 0, e->stream, e->d_seg, e->sr, lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first,
                            (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
-                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e));
+                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
+                           publish ? ++e->flag_seq : 0u, e->d_done_ctr);
         HIP_TRY(hipGetLastError());
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
+    return MC_OK;
+}
+
+// The output of the period is on the host once its last kernel has published the sequence number: spin on the
+// mapped word (a JACK callback blocks here anyway; the reference blocks in cudaEventSynchronize, conv.cu:455);
+// fall back to a stream sync if it does not arrive in time.
+int wait_period(mc_engine* e) {
+    if (!e->spin_wait) {
+        HIP_TRY(hipEventSynchronize(e->ev_tail));
+        return MC_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) return fail(MC_ERR_HIP, "period did not complete");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
     return MC_OK;
 }
 
@@ -912,19 +937,9 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     // the output of THIS block is on the host once k_tail1 has published its sequence number; the speculative
     // sweep keeps running.  Spin on the mapped word (a JACK callback blocks here anyway; the reference blocks in
     // cudaEventSynchronize, conv.cu:455); fall back to a stream sync if it does not arrive in time.
-    if (e->spin_wait) {
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) {
-            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-                HIP_TRY(hipStreamSynchronize(e->stream));
-                if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) return fail(MC_ERR_HIP, "period did not complete");
-                break;
-            }
-            __builtin_ia32_pause();
-        }
-    } else {
-        HIP_TRY(hipEventSynchronize(e->ev_tail));
+    {
+        int rc = wait_period(e);
+        if (rc) return rc;
     }
     std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
     std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * MC_B);
@@ -947,6 +962,27 @@ int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, 
     HIP_TRY(hipMemcpyAsync(e->h_io + 2 * cap, e->d_io[2], bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_io + 3 * cap, e->d_io[3], bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    std::memcpy(outL, e->h_io + 2 * cap, bytes);
+    std::memcpy(outR, e->h_io + 3 * cap, bytes);
+    return MC_OK;
+}
+
+// One JACK period of 512 / 1024 frames (pm = 2 / 4 blocks): the batch pipeline with zero-copy I/O - k_fwd reads the
+// period from mapped host memory, k_post writes the output there and raises the completion flag.
+int process_period(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
+    if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
+    if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
+    const int T = e->pm;
+    const size_t bytes = (size_t)T * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
+    std::memcpy(e->h_io + 0 * cap, in1, bytes);
+    std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    int rc = run_front(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, T, nullptr, 0, T);
+    if (rc) return rc;
+    rc = run_back(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, nullptr, e->hd_io + 2 * cap, e->hd_io + 3 * cap, T, true);
+    if (rc) return rc;
+    if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
+    rc = wait_period(e);
+    if (rc) return rc;
     std::memcpy(outL, e->h_io + 2 * cap, bytes);
     std::memcpy(outR, e->h_io + 3 * cap, bytes);
     return MC_OK;
@@ -1067,6 +1103,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipHostMalloc(&e->h_flag, 64, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
     *e->h_flag = 0;
+    ENG_TRY(hipMalloc(&e->d_done_ctr, sizeof(unsigned)));
+    ENG_TRY(hipMemset(e->d_done_ctr, 0, sizeof(unsigned)));
     if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
     for (int i = 0; i < kStageBufs; i++) {
         ENG_TRY(hipHostMalloc(&e->h_ptab[i], sizeof(BlockParams) * (size_t)e->Tmax, hipHostMallocDefault));
@@ -1111,6 +1149,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_wet);
     (void)hipFree(e->d_cring);
     (void)hipFree(e->d_ctot);
+    (void)hipFree(e->d_done_ctr);
     (void)hipFree(e->d_res_mac);
     (void)hipFree(e->d_res_fix);
     (void)hipFree(e->d_xhist);
@@ -1272,8 +1311,8 @@ int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, fl
     // the reference brackets its GPU work with events (conv.cu:299-302, 454-462); the call below
     // returns only when the output is on the host, so a host clock around it measures a superset
     const auto t0 = std::chrono::steady_clock::now();
-    // 256-frame periods take the fused single-block path; 512 / 1024 run as one small batch
-    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR) : process_host(e, in1, in2, outL, outR, e->pm);
+    // 256-frame periods take the fused single-block path; 512 / 1024 run as one small zero-copy batch
+    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR) : process_period(e, in1, in2, outL, outR);
     if (rc) return rc;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (++e->nruns > 0) e->runtime_ms += ms;  // first 10 calls discarded, conv.h:80

@@ -7,15 +7,16 @@ from cuda_audio_amd.engine import Convolution
 from cuda_audio_amd.synth import make_input, make_ir
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-c = Convolution("lat", 524288, max_batch=4)
+period = int(sys.argv[2]) if len(sys.argv) > 2 else 256  # JACK period: 256, 512 or 1024 frames
+c = Convolution("lat", 524288, max_batch=4, period=period)
 c.prepare(0, make_ir(441000, seed=5678))
 c.prepare(1, make_ir(441000, seed=5680))
 c.cc[1].value.select = 1
-x = make_input(256)
+x = make_input(period)
 for _ in range(int(os.environ.get("WARM", "100"))):
     c.onProcess(x[0], x[1])
 t0 = time.perf_counter()
 for _ in range(n):
     c.onProcess(x[0], x[1])
 dt = (time.perf_counter() - t0) / n
-print(f"wall_us_per_block {dt*1e6:.1f} rtf {256/44100/dt:.1f} avgRuntime_ms {c.avgRuntime():.4f}")
+print(f"wall_us_per_block {dt*1e6:.1f} rtf {period/44100/dt:.1f} avgRuntime_ms {c.avgRuntime():.4f}")
