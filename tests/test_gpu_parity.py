@@ -1009,3 +1009,60 @@ def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, 
     c.process_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
     for c in engines:
         c.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("mode,period", [("jack", 256), ("batch", 256), ("jack", 512)], ids=["jack", "batch", "jack512"])
+def test_random_controller_traffic(oracle_mod, gpu_lib, seed, mode, period):
+    """Randomised live control: every few calls a random controller message (select, predelay, dry, wet, speed, pans,
+    level) on a random half, applied to the restatement and to the engine through handleCC.  Three IRs, so the
+    engine's three voices can hold every IR that is still sounding."""
+    import ctypes as C
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    rng = np.random.default_rng(seed)
+    pm = period // 256
+    ncalls, n_ref = 260 // pm, 4096
+    nb = ncalls * pm
+    x = make_input(nb * 256)
+    irs = [make_ir(2500, seed=11, norm=0.05), make_ir(3072, seed=22, norm=0.05), make_ir(1800, seed=33, norm=0.05)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=16 * pm, period=period)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    cmap = (21, 22, 23, 24, 25, 26, 27, 28)
+    arr = (C.c_uint8 * 8)(*cmap)
+    events = {}
+    q = 0
+    while q < ncalls:
+        ctl = int(rng.choice(cmap))
+        val = int(rng.integers(0, 128))
+        if ctl == 25:
+            val = int(rng.integers(0, 4))   # speed: cross-fades of at most 24 calls
+        if ctl == 28:
+            val = int(rng.integers(64, 128))  # level: keep the wet sum inside the clamp (Q4)
+        events.setdefault(q, []).append((int(rng.integers(0, 2)), ctl, val))
+        q += int(rng.integers(1, 9))
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    q = 0
+    while q < ncalls:
+        for half, ctl, val in events.get(q, []):
+            oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
+            assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
+        n = 1
+        if mode == "batch":
+            n = min(16, min([e for e in events if e > q] + [ncalls]) - q)
+        s = slice(q * period, (q + n) * period)
+        want[:, s] = ref.process(x[0, s], x[1, s], block=period)
+        if mode == "jack":
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        q += n
+    c.close()
+    assert np.abs(want).max() < 1.5
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"seed {seed}: rms {err:.3e} (signal {rms(want):.3e})"
