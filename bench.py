@@ -54,6 +54,9 @@ def parse():
                          "data-path collective, the slices are gathered to rank 0 (default: batch throughput). partitions: "
                          "every GPU holds 1/N of the IR partitions and the partial wet blocks are summed with RCCL (the "
                          "layout that also shortens a single real-time period)")
+    ap.add_argument("--exchange", choices=["gather", "none"], default="gather",
+                    help="--shard blocks: gather the finished slices on rank 0 (default; overlapped with the next batch) or "
+                         "leave every rank's slice where it was computed")
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
                     help="--shard partitions: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
@@ -118,6 +121,12 @@ def cpu_baseline(ir, ir_b, x, seconds):
 
 def main():
     a = parse()
+    # The contract is ONE JSON line on stdout.  Libraries below us write there too (gloo's connection banner, RCCL
+    # at some debug levels): from here on everything that goes to file descriptor 1 lands on stderr, and the JSON
+    # line is written to the original stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -190,7 +199,7 @@ def main():
     # block slices: this rank's output blocks of a batch (double-buffered), gathered on rank 0
     d_slices = [torch.zeros(2, count * BLOCK, device=dev) for _ in range(2)] if by_blocks else None
     d_gather = ([[torch.zeros(2, count * BLOCK, device=dev) for _ in range(world)] for _ in range(2)]
-                if by_blocks and rank == 0 and shard_world == world else None)
+                if by_blocks and rank == 0 and shard_world == world and a.exchange == "gather" else None)
     # one compute stream for the engine, the torch ops and (as the stream the collectives order themselves
     # against) RCCL: partial -> reduce -> finish are then ordered by the streams, not by host synchronisation
     torch.cuda.synchronize()
@@ -219,7 +228,7 @@ def main():
 
     def gather_slices(sl, k):
         # the only exchange of the block-sliced layout: count * 2 KB per rank and batch to rank 0, off the data path
-        if shard_world != world:  # one emulated rank of several: nothing to gather
+        if shard_world != world or a.exchange == "none":  # (one emulated rank of several: nothing to gather)
             return _Done()
         if a.backend == "gloo":  # rehearsal: through host memory
             h = sl.cpu()
@@ -453,8 +462,9 @@ def main():
                 "mode": a.mode,
                 "parallelism": "single GPU" if not sharded else
                 (f"output blocks of every batch sliced over {world} GPU(s) ({count} blocks each, every GPU holds the whole IR "
-                 f"and transforms the whole input); no data-path collective, slices gathered to rank 0 "
-                 f"({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})" if by_blocks else
+                 f"and transforms the whole input); no data-path collective, "
+                 + (f"slices gathered to rank 0 ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})" if a.exchange == "gather"
+                    else "slices left on their ranks") if by_blocks else
                  f"IR partitions sharded over {world} GPU(s) + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} {a.collective} of partial wet blocks")
                 + ("" if a.no_overlap else ", overlapped with the next batch"),
                 "shard": (a.shard if sharded else None),
@@ -465,7 +475,7 @@ def main():
         }
         if sharded_check is not None:
             line["sharded_check"] = sharded_check
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     eng.close()
     if sharded:
         dist.destroy_process_group()
