@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
                                              uint2* __restrict__ fdl16,  // fp16 mirror of the delay line or null
                                              float* __restrict__ xhist, int xr,  // [2][xr] input history ring or null
                                              float4* __restrict__ gring, int rc,  // [MC_MAXV][rc] gains of past blocks
-                                             int64_t tabs0) {                     // absolute block of t = 0
+                                             int64_t tabs0,                       // absolute block of t = 0
+                                             int need_a0, int need_a1, int need_b0) {
+    // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
+    // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
@@ -92,9 +95,15 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb0 = blockIdx.x * FWD_TILE;
     float2* lds = s_fft[wave];
+    auto needed = [&](int t) { return (t >= need_a0 && t < need_a1) || t >= need_b0; };
     for (int it = 0; it < FWD_TILE / 4; it++) {
         const int tb = it * 4 + wave;  // block within tile
         const int t = tb0 + tb;
+        if (t < T && !needed(t)) {  // wave-uniform
+            if (sums && lane == 0) sums[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();  // the one workgroup barrier of an iteration
+            continue;
+        }
         float2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = make_float2(0.f, 0.f);
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
                 }
             }
         }
-        fft512_wave<-1>(v, lds, s_tw, lane);
+        fft512_wave<-1, false>(v, lds, s_tw, lane);  // wave-private LDS: waves that skip a block stay out of it
         if (t < T) {
             // two-for-one split of the packed transform (true spectra; the
             // reference's DC/Nyquist shortcuts Q1/Q2 are rank-1 terms added in k_post)
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
-        if (t < T) {
+        if (t < T && needed(t)) {
             const size_t at = (size_t)k * ring + ((slot0 + t) & (ring - 1));
             fdl[at] = s_tile[k][tb];
             if (fdl16) fdl16[at] = pack_half4(s_tile[k][tb], FDL16_SCALE);

@@ -153,6 +153,7 @@ struct mc_engine {
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
+    int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
     bool uniform_valid[2] = {false, false};
     BlockParams uniform_bp[2];
 
@@ -208,6 +209,7 @@ int zero_state(mc_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->res_end = e->epoch_b0 = e->cur_delay = 0;
     e->sliced = false;
+    e->slice_first = -1;
     for (int i = 0; i < 2; i++)
         for (int v = 0; v < MC_MAXV; v++) e->voice[i][v] = mc_engine::VoiceSlot();
     for (int v = 0; v < MC_MAXV; v++) {
@@ -647,7 +649,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay) {
         hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
-                           (int64_t)0);
+                           (int64_t)0, 0, Tc, Tc);
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
@@ -705,7 +707,19 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         halo = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
         halo = (int)std::min<uint64_t>((uint64_t)halo, e->t_front + (uint64_t)first);  // the stream starts at block 0
         if (count + halo > e->Tmax) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds max_batch %d", count, halo, e->Tmax);
+        if (e->sliced && e->slice_first != first) return fail(MC_ERR_STATE, "the slice start moved from block %d to %d (mc_reset first)", e->slice_first, first);
         e->sliced = true;
+        e->slice_first = first;
+    }
+    // Blocks of this batch that some window of this engine can reach - now (its slice and what lies within one
+    // reference length + the largest predelay before it) or from the next call (the same distance before the next
+    // slice start).  Only those are transformed; a whole-batch call needs them all.
+    int need_a0 = 0, need_a1 = T, need_b0 = T;
+    if (slice) {
+        const int64_t reach = (int64_t)(e->cfg.n_ref / MC_B) + MC_MAX_PREDELAY / MC_B + 2;
+        need_a0 = (int)std::max<int64_t>(0, (int64_t)first - reach);
+        need_a1 = first + count;
+        need_b0 = (int)std::max<int64_t>(0, std::min<int64_t>(T, (int64_t)T + first - reach));
     }
     const uint64_t wblock = e->t_front + (uint64_t)first - (uint64_t)halo;  // first block of the window (absolute)
     st.ctx.first = first;
@@ -722,7 +736,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // K1: all T blocks
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
-                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front);
+                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0);
     if (e->ktiming && e->kev_n == kEvPool) {
         int rc = drain_kernel_events(e);
         if (rc) return rc;
@@ -1212,7 +1226,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (er == hipSuccess) {
         hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
-                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0);
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P);
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);

@@ -943,14 +943,17 @@ def test_predelay_change_sharded(oracle_mod, gpu_lib):
         s.close()
 
 
-@pytest.mark.parametrize("n_ref,taps,pd,period", [(8192, (5000, 4000), 0, 256), (8192, (5000, 4000), 700, 256),
-                                                  (4096, (3072, 3072), 1024, 256), (8192, (6000, 4000), 300, 512),
-                                                  (16384, (9000, 15000), 8192, 256)],
-                         ids=["pd0", "pd700", "pd1024_taildrop", "period512", "max_predelay"])
-def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, pd, period):
+@pytest.mark.parametrize("n_ref,taps,pd,period,world,T", [(8192, (5000, 4000), 0, 256, 3, 48), (8192, (5000, 4000), 700, 256, 3, 48),
+                                                          (4096, (3072, 3072), 1024, 256, 3, 48), (8192, (6000, 4000), 300, 512, 3, 48),
+                                                          (16384, (9000, 15000), 8192, 256, 3, 48),
+                                                          (4096, (3072, 3072), 1024, 256, 4, 256), (4096, (2500, 3000), 0, 256, 8, 256)],
+                         ids=["pd0", "pd700", "pd1024_taildrop", "period512", "max_predelay", "long_batches_taildrop", "long_batches_8way"])
+def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, pd, period, world, T):
     """Block-sliced operation (throughput scaling without a collective): three engines are fed the same batches and
     each finishes its slice of the output blocks.  The concatenation equals the reference - through the cold-start
-    ramp (per-slot gains), an IR switch with cross-fade and a wet change, for slices that start inside the batch."""
+    ramp (per-slot gains), an IR switch with cross-fade and a wet change, for slices that start inside the batch.
+    With batches longer than the reference length plus the largest predelay an engine transforms only the blocks its
+    windows can reach (the long_batches cases)."""
     import torch
 
     from cuda_audio_amd._lib import McError
@@ -958,7 +961,7 @@ def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, 
     from cuda_audio_amd.synth import make_input, make_ir
 
     pm = period // 256
-    world, T, nbat = 3, 48, 5
+    nbat = 5 if T < 100 else 3
     nb = T * nbat
     x = make_input(nb * 256)
     irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05), make_ir(taps[0] - 500, seed=33, norm=0.05)]
