@@ -126,12 +126,13 @@ int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2
                             uint64_t nblocks);
 /* Block-sliced operation - scaling batch throughput over GPUs without a data-path collective.  The output blocks
  * of a batch are independent given the input, so G engines (one per GPU) are fed the SAME batch and each finishes
- * `count` output blocks starting at block `first` of it into d_outL/d_outR (count*256 floats each).  Every engine
- * still transforms all nblocks inputs (its delay line, gains, Q1/Q2 sums and histories stay complete: ~2% of the
- * work); the partition sums and inverse transforms run only over the slice plus the <= 33 blocks before it that the
- * overlap-add and the predelay reach back to (count + reach-back <= max_batch).  An engine that has been called
- * with a proper slice keeps no wet history outside its slices: until mc_reset it accepts only sliced calls, and a
- * predelay change is refused (MC_ERR_STATE).  first = 0, count = nblocks is mc_process_batch_device. */
+ * `count` output blocks starting at block `first` of it into d_outL/d_outR (count*256 floats each).  An engine
+ * transforms only the input blocks its own windows can reach (its slice, n_ref + 8192 frames before it and the
+ * same distance before the next call's slice); the partition sums and inverse transforms run over the slice plus
+ * the <= 33 blocks before it that the overlap-add and the predelay reach back to (count + reach-back <=
+ * max_batch).  Consequences: `first` must be the same in every call, and an engine that has been called with a
+ * proper slice accepts only sliced calls and no predelay change until mc_reset (MC_ERR_STATE otherwise).
+ * first = 0, count = nblocks is mc_process_batch_device. */
 int mc_process_batch_slice_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
                                   uint64_t nblocks, uint64_t first, uint64_t count);
 /* Sharded operation: d_partial receives this engine's share of the wet signal,
