@@ -1249,3 +1249,317 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+// ---------------------------------------------------------------------------
+// JACK periods of 512 / 1024 frames (PM = 2 / 4 blocks per call): the same
+// idea as k_tail1 for PM blocks at once.  k_mac_stream has summed partitions
+// p >= PM for the PM blocks of the call in the shadow of the previous period
+// (they pair only with blocks already in the delay line); this kernel does the
+// rest in one workgroup: wave w transforms block w, every thread adds the
+// PM x PM low-partition products of its bin (new blocks from LDS, the PM - 1
+// newest old blocks from the delay line), wave w inverts block w, then
+// overlap-add, Q1/Q2 prefix, predelay, Q8, clamp, dry for PM x 256 frames.
+// The blocks of a call share one parameter entry (the reference advances its
+// cross-fade once per call) and the Q1/Q2/Q8 windows start at the call.
+// ---------------------------------------------------------------------------
+template <int PM>
+__global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, const float* __restrict__ in2, VoiceSet vset,
+                                               int pstride_ir, float4* __restrict__ fdl, float4* __restrict__ slotgain, int ring,
+                                               int slot0, const float4* __restrict__ part, int nsum,
+                                               const BlockParams* __restrict__ ptab, float* __restrict__ seg, int sr,
+                                               float* __restrict__ wet, int wr, double* __restrict__ cring, int rc, VoiceSums vs,
+                                               double inv_n, int compat, int64_t tabs0, int64_t predelay, int64_t n_ref,
+                                               float* __restrict__ outL, float* __restrict__ outR,
+                                               const float2* __restrict__ g_tw, TailDrop td, uint2* __restrict__ fdl16,
+                                               unsigned* __restrict__ done_flag, unsigned seq, Retired ret) {
+    static_assert(PM == 2 || PM == 4, "one wave per block of the call");
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[PM][FFT_WAVE_LDS];
+    __shared__ float4 s_xy[PM][MC_NB];  // spectra {X1, X2} of the new blocks, then {Y_L, Y_R}
+    __shared__ float s_wet[2][PM * MC_B];
+    __shared__ float s_in[2][PM * MC_B];
+    __shared__ double s_d[PM][4];  // Q1/Q2 terms of the blocks, then their running prefix sums
+    __shared__ float4 s_sa[PM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlockParams& bp = ptab[0];
+    const int m = tid;
+    const int64_t tau0 = tabs0 * MC_B;
+
+    // ---- loads with addresses known at entry (one round of memory latency; see k_tail1) ----
+    float xin[PM][2];
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        xin[j][0] = in1[j * MC_B + tid];
+        xin[j][1] = in2[j * MC_B + tid];
+    }
+    const float2 tw0 = g_tw[tid], tw1 = g_tw[tid + 256];
+    float4 ysum[PM];
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        ysum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* src = part + ((size_t)j * MC_NB + tid) * nsum;
+        for (int c = 0; c < nsum; c++) {
+            const float4 a = src[c];
+            ysum[j].x += a.x;
+            ysum[j].y += a.y;
+            ysum[j].z += a.z;
+            ysum[j].w += a.w;
+        }
+    }
+    float4 xold[PM];  // xold[q] = spectrum of the block q before the call, q = 1 .. PM-1
+#pragma unroll
+    for (int q = 1; q < PM; q++) xold[q] = fdl[(size_t)tid * ring + ((slot0 - q) & (ring - 1))];
+    const float* prv = seg + (size_t)((tabs0 - 1) & (sr - 1)) * 2 * FFT_N;
+    const float prvL = prv[MC_B + m], prvR = prv[FFT_N + MC_B + m];
+    float dw[PM][2];
+    float2 ra[PM], rb[PM];
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        const int64_t tau = tau0 + j * MC_B + m, u = tau - predelay;
+        dw[j][0] = dw[j][1] = 0.f;
+        if (u >= 0 && u < tau0) {
+            dw[j][0] = wet[(size_t)(u & (wr - 1))];
+            dw[j][1] = wet[(size_t)wr + (u & (wr - 1))];
+        }
+        ra[j] = rb[j] = make_float2(0.f, 0.f);
+        if (tau < ret.end) {
+            ra[j] = retired_at(ret.mac, ret.rr, tau);
+            rb[j] = retired_at(ret.fix, ret.rr, tau);
+        }
+    }
+    double cprev[4] = {0, 0, 0, 0};
+    if (tid == 0 && tabs0 > 0) {
+        const double* pp = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) cprev[c] = pp[c];
+    }
+    s_tw[tid] = tw0;
+    s_tw[tid + 256] = tw1;
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        s_in[0][j * MC_B + tid] = xin[j][0];
+        s_in[1][j * MC_B + tid] = xin[j][1];
+    }
+    __syncthreads();
+
+    // ---- wave w: forward transform of block w ----
+    float4 xs_keep[4];
+    if (wave < PM) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = make_float2(s_in[0][wave * MC_B + lane + 64 * r], s_in[1][wave * MC_B + lane + 64 * r]);
+#pragma unroll
+        for (int r = 4; r < 8; r++) v[r] = make_float2(0.f, 0.f);
+        float2* lds = s_fft[wave];
+        fft512_wave<-1, false>(v, lds, s_tw, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = lane + 64 * j;
+            const float2 za = lds[k], zb = lds[(FFT_N - k) & (FFT_N - 1)];
+            float2 x1, x2;
+            if (k == 0) {
+                const float2 zn = lds[MC_B];
+                x1 = make_float2(za.x, zn.x);
+                x2 = make_float2(za.y, zn.y);
+                s_sa[wave] = make_float4(za.x, za.y, zn.x, zn.y);
+            } else {
+                x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
+                x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
+            }
+            const float4 xs = make_float4(x1.x, x1.y, x2.x, x2.y);
+            s_xy[wave][k] = xs;
+            xs_keep[j] = xs;
+        }
+    }
+    __syncthreads();
+
+    // ---- bin tid: partitions p < PM of every voice against blocks j - p (new: LDS, old: delay line) ----
+    {
+        const int k = tid;
+        float4 xnew[PM], y[PM];
+#pragma unroll
+        for (int j = 0; j < PM; j++) {
+            xnew[j] = s_xy[j][k];
+            y[j] = ysum[j];
+        }
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+            if (vi >= vset.n) break;
+            const int row = vset.vid[vi];
+            const float* gn = ptab->g[row];
+            float4 h0[PM], h1[PM], gold[PM];
+#pragma unroll
+            for (int p = 0; p < PM; p++) {
+                h0[p] = vset.H0[vi][(size_t)k * pstride_ir + p];
+                h1[p] = vset.H1[vi][(size_t)k * pstride_ir + p];
+            }
+#pragma unroll
+            for (int q = 1; q < PM; q++) gold[q] = slotgain[(size_t)row * ring + ((slot0 - q) & (ring - 1))];
+#pragma unroll
+            for (int j = 0; j < PM; j++) {
+#pragma unroll
+                for (int p = 0; p < PM; p++) {
+                    const float4 x = (p <= j) ? xnew[(p <= j) ? j - p : 0] : xold[(p > j) ? p - j : 1];
+                    const float4 g = (p <= j) ? make_float4(gn[0], gn[1], gn[2], gn[3]) : gold[(p > j) ? p - j : 1];
+                    float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                    if (k == 0) {
+                        cmac<true>(a0, h0[p].x, h0[p].y, x.x, x.y);
+                        cmac<true>(a1, h1[p].x, h1[p].y, x.z, x.w);
+                        cmac<true>(a2, h0[p].z, h0[p].w, x.x, x.y);
+                        cmac<true>(a3, h1[p].z, h1[p].w, x.z, x.w);
+                    } else {
+                        cmac<false>(a0, h0[p].x, h0[p].y, x.x, x.y);
+                        cmac<false>(a1, h1[p].x, h1[p].y, x.z, x.w);
+                        cmac<false>(a2, h0[p].z, h0[p].w, x.x, x.y);
+                        cmac<false>(a3, h1[p].z, h1[p].w, x.z, x.w);
+                    }
+                    y[j].x += g.x * a0.x + g.y * a1.x;
+                    y[j].y += g.x * a0.y + g.y * a1.y;
+                    y[j].z += g.z * a2.x + g.w * a3.x;
+                    y[j].w += g.z * a2.y + g.w * a3.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PM; j++) s_xy[j][k] = y[j];
+    }
+    __syncthreads();
+
+    // ---- wave w: inverse transform of block w, then (lane 0) the block's Q1/Q2 terms ----
+    if (wave < PM) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n = lane + 64 * r;
+            float2 w;
+            if (n == 0) {
+                const float4 y = s_xy[wave][0];
+                w = make_float2(y.x, y.z);
+            } else if (n == MC_B) {
+                const float4 y = s_xy[wave][0];
+                w = make_float2(y.y, y.w);
+            } else if (n < MC_B) {
+                const float4 y = s_xy[wave][n];
+                w = make_float2(y.x - y.w, y.y + y.z);
+            } else {
+                const float4 y = s_xy[wave][FFT_N - n];
+                w = make_float2(y.x + y.w, -y.y + y.z);
+            }
+            v[r] = w;
+        }
+        fft512_wave<+1, false>(v, s_fft[wave], s_tw, lane);
+        if (lane == 0) {
+            double d[4] = {0, 0, 0, 0};
+            if (compat) corr_terms(s_sa[wave], bp, vs, inv_n, d);
+            for (int c = 0; c < 4; c++) s_d[wave][c] = d[c];
+        }
+    }
+    __syncthreads();
+
+    // ---- overlap-add chain through the call; running Q1/Q2 prefix ----
+    const float sc = 1.0f / FFT_N;
+    float seg_lo[PM][2], seg_hi[PM][2], own[PM][2];
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        const float2 lo = s_fft[j][m], hi = s_fft[j][MC_B + m];
+        seg_lo[j][0] = lo.x * sc;
+        seg_lo[j][1] = lo.y * sc;
+        seg_hi[j][0] = hi.x * sc;
+        seg_hi[j][1] = hi.y * sc;
+        own[j][0] = seg_lo[j][0] + (j == 0 ? prvL : seg_hi[j > 0 ? j - 1 : 0][0]);
+        own[j][1] = seg_lo[j][1] + (j == 0 ? prvR : seg_hi[j > 0 ? j - 1 : 0][1]);
+        s_wet[0][j * MC_B + m] = own[j][0];
+        s_wet[1][j * MC_B + m] = own[j][1];
+    }
+    if (tid == 0) {
+        double run[4] = {cprev[0], cprev[1], cprev[2], cprev[3]};
+#pragma unroll
+        for (int j = 0; j < PM; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                run[c] += s_d[j][c];
+                s_d[j][c] = run[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- predelay, residuals, Q1/Q2 windows (from the call start), Q8, clamp, dry ----
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        const int64_t tau = tau0 + j * MC_B + m, u = tau - predelay;
+        float wl = dw[j][0], wr_ = dw[j][1];
+        if (u >= tau0) {
+            wl = s_wet[0][u - tau0];
+            wr_ = s_wet[1][u - tau0];
+        }
+        wl += ra[j].x + rb[j].x;
+        wr_ += ra[j].y + rb[j].y;
+        double cl = 0.0, cr = 0.0;
+        if (compat && u >= 0) {
+            const int64_t thi = ((u >> 8) / PM + 1) * PM - 1;  // last block of the call that holds sample u
+            const int64_t v = tau - n_ref;
+            int64_t tlo = v >= 0 ? ((v >> 8) / PM + 1) * PM - 1 : -1;
+            if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
+            if (thi > tlo) {
+                double a[4], b[4] = {0, 0, 0, 0};
+                if (thi >= tabs0) {
+                    for (int c = 0; c < 4; c++) a[c] = s_d[thi - tabs0][c];
+                } else {
+                    const double* pa = cring + (size_t)(thi & (rc - 1)) * 4;
+                    for (int c = 0; c < 4; c++) a[c] = pa[c];
+                }
+                if (tlo >= 0) {
+                    const double* pb = cring + (size_t)(tlo & (rc - 1)) * 4;
+                    for (int c = 0; c < 4; c++) b[c] = pb[c];
+                }
+                const double sg = (u & 1) ? -1.0 : 1.0;
+                cl = (a[0] - b[0]) + sg * (a[2] - b[2]);
+                cr = (a[1] - b[1]) + sg * (a[3] - b[3]);
+            }
+        }
+        const float x1 = xin[j][0], x2 = xin[j][1];
+        if (td.on) {
+            float dl, dr;
+            tail_drop(td, tau, tau0, PM, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, PM, ret.b0, INT64_MAX);
+            wl -= dl;
+            wr_ -= dr;
+        }
+        const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
+        const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
+        outL[j * MC_B + m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
+        outR[j * MC_B + m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+    }
+    // ---- state for later periods (no global store before this point: see k_tail1) ----
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        const int64_t tau = tau0 + j * MC_B + m;
+        float* cur = seg + (size_t)((tabs0 + j) & (sr - 1)) * 2 * FFT_N;
+        cur[m] = seg_lo[j][0];
+        cur[MC_B + m] = seg_hi[j][0];
+        cur[FFT_N + m] = seg_lo[j][1];
+        cur[FFT_N + MC_B + m] = seg_hi[j][1];
+        wet[(size_t)(tau & (wr - 1))] = own[j][0];
+        wet[(size_t)wr + (tau & (wr - 1))] = own[j][1];
+        write_history(td, tau, tabs0 + j, m, xin[j][0], xin[j][1], bp, rc);
+    }
+    if (wave < PM) {
+        const int slot = (slot0 + wave) & (ring - 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = lane + 64 * j;
+            fdl[(size_t)k * ring + slot] = xs_keep[j];
+            if (fdl16) fdl16[(size_t)k * ring + slot] = pack_half4(xs_keep[j], FDL16_SCALE);
+        }
+        if (lane < MC_MAXV)
+            slotgain[(size_t)lane * ring + slot] = make_float4(bp.g[lane][0], bp.g[lane][1], bp.g[lane][2], bp.g[lane][3]);
+    }
+    if (tid < PM) {
+        double* o = cring + (size_t)((tabs0 + tid) & (rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) o[c] = s_d[tid][c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}

@@ -1002,6 +1002,122 @@ int process_period(mc_engine* e, const float* in1, const float* in2, float* outL
     return MC_OK;
 }
 
+// One JACK period of 512 / 1024 frames on an unsharded engine: the streaming MAC over partitions >= pm (summed
+// speculatively in the shadow of the previous period, as in process_one) and the fused k_tailp.
+int process_period_fused(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
+    if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
+    if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
+    if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
+    const int pm = e->pm;
+    const size_t bytes = (size_t)pm * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
+    std::memcpy(e->h_io + 0 * cap, in1, bytes);
+    std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    Staged st;
+    {
+        mc_cc_value cc[2];
+        int rc = sample_params(e, cc);
+        if (!rc) rc = retire_epoch(e, cc[0].predelay);
+        if (!rc) rc = stage_params(e, pm, cc, &st);
+        if (rc) return rc;
+    }
+    if (st.ctx.pstride != 0) return fail(MC_ERR_STATE, "the blocks of one period must share their parameters");
+    const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
+
+    ActiveVoice sweep[MC_MAXV];
+    int hi[MC_MAXV], nsweep = 0;
+    VoiceSet vset;
+    std::memset(&vset, 0, sizeof(vset));
+    for (int a = 0; a < st.nact; a++) {
+        const int pe = st.act[a].p_end;
+        if (pe <= 0) continue;
+        vset.vid[vset.n] = st.act[a].v;
+        vset.H0[vset.n] = st.act[a].ir0->d_H;
+        vset.H1[vset.n] = st.act[a].ir1->d_H;
+        vset.n++;
+        if (pe > pm) {
+            sweep[nsweep] = st.act[a];
+            hi[nsweep] = pe;
+            nsweep++;
+        }
+    }
+    const int nsum = std::max(1, nsweep) * e->nchunk;
+
+    // partitions >= pm of the pm blocks starting at `blk` pair only with blocks before blk
+    auto launch_mac = [&](uint64_t blk) -> int {
+        const bool timed = e->ktiming;
+        if (timed) {
+            if (e->kev_n == kEvPool) {
+                int rc = drain_kernel_events(e);
+                if (rc) return rc;
+            }
+            e->kev_blocks[e->kev_n] = (uint32_t)pm;
+            HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
+        }
+        const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
+        int swept = 0;
+        for (int a = 0; a < nsweep; a++) {
+            ActiveVoice av = sweep[a];
+            av.uniform = e->gain_change_block[av.v] + (uint64_t)hi[a] <= blk && e->gain_change_block[av.v] < blk;
+            launch_mac_stream(e, av, pm, hi[a], pm, bslot0, nsum, a * e->nchunk);
+            swept = std::max(swept, hi[a]);
+        }
+        if (timed) {
+            HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
+            e->kev_n++;
+            e->ks.resident = 0;
+            e->ks.partitions = (uint32_t)swept;
+        }
+        return MC_OK;
+    };
+    bool spec_hit = e->spec_valid && e->spec_block == e->t_front && e->spec_nact == nsweep;
+    if (spec_hit)
+        for (int a = 0; a < nsweep && spec_hit; a++)
+            spec_hit = e->spec_vir[0][a] == st.ctx.vir[0][sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][sweep[a].v];
+    if (!spec_hit) {
+        if (nsweep) {
+            int rc = launch_mac(e->t_front);
+            if (rc) return rc;
+        } else {
+            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)pm * MC_NB * nsum, e->stream));
+        }
+    }
+    e->spec_valid = false;
+#define MC_LAUNCH_TAILP(PM)                                                                                                  \
+    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, e->hd_io + 0 * cap, e->hd_io + 1 * cap, vset, e->Pstride, \
+                       e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr,  \
+                       e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,     \
+                       (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,      \
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq, make_retired(e))
+    if (pm == 2)
+        MC_LAUNCH_TAILP(2);
+    else
+        MC_LAUNCH_TAILP(4);
+#undef MC_LAUNCH_TAILP
+    HIP_TRY(hipGetLastError());
+    if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
+    e->batch_seq++;
+    e->t_front += (uint64_t)pm;
+    e->t_abs = e->t_front;
+    if (e->speculate && nsweep) {
+        int rc = launch_mac(e->t_front);
+        if (rc) return rc;
+        e->spec_valid = true;
+        e->spec_block = e->t_front;
+        e->spec_nact = nsweep;
+        for (int a = 0; a < nsweep; a++) {
+            e->spec_vir[0][a] = st.ctx.vir[0][sweep[a].v];
+            e->spec_vir[1][a] = st.ctx.vir[1][sweep[a].v];
+        }
+    }
+    {
+        int rc = wait_period(e);
+        if (rc) return rc;
+    }
+    std::memcpy(outL, e->h_io + 2 * cap, bytes);
+    std::memcpy(outR, e->h_io + 3 * cap, bytes);
+    return MC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1326,7 +1442,10 @@ int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, fl
     // returns only when the output is on the host, so a host clock around it measures a superset
     const auto t0 = std::chrono::steady_clock::now();
     // 256-frame periods take the fused single-block path; 512 / 1024 run as one small zero-copy batch
-    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR) : process_period(e, in1, in2, outL, outR);
+    // (partition shards keep the batch kernels: their low partitions are not the IR's first ones)
+    const bool whole_ir = e->cfg.part_begin == 0 && e->cfg.part_end == 0;
+    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR)
+                        : (whole_ir ? process_period_fused(e, in1, in2, outL, outR) : process_period(e, in1, in2, outL, outR));
     if (rc) return rc;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (++e->nruns > 0) e->runtime_ms += ms;  // first 10 calls discarded, conv.h:80
