@@ -365,6 +365,24 @@ def main():
             "note": "event-bracketed single launches include ~3 us of event overhead; the rocprofv3 figure is the "
                     "kernel's average duration in profiles/r1_jack_kernel_stats.csv (same path, same IRs)",
         }
+        # the periods the reference's run scripts start jackd with (512 / 1024 frames per call)
+        longer = {}
+        for period in (512, 1024):
+            if T % (period // BLOCK):
+                continue
+            eng.set_period(period)
+            pb_ = [np.ascontiguousarray(xs[0, :period]), np.ascontiguousarray(xs[1, :period]),
+                   np.zeros(period, np.float32), np.zeros(period, np.float32)]
+            pp_ = [b.ctypes.data_as(fp) for b in pb_]
+            for _ in range(200):
+                L.mc_process(eng._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
+            t1 = time.perf_counter()
+            for _ in range(1000):
+                L.mc_process(eng._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
+            lp = (time.perf_counter() - t1) / 1000
+            longer[str(period)] = {"us_per_call_wall": round(lp * 1e6, 2), "rtf": round(period / FS / lp, 1)}
+        eng.set_period(BLOCK)
+        latency["longer_periods"] = longer
 
     # Untimed: the sharded pipeline exactly as timed above (two batches in flight, collective on RCCL's stream)
     # against an unsharded engine fed the same batches from the same cold state, on rank 0.
