@@ -766,6 +766,16 @@ def test_longer_jack_periods(oracle_mod, gpu_lib, period, pd, taps):
     apply_params(c, p0, p1, False)
     got2 = c.process(x[0], x[1])
     assert rms(got2 - want) <= RMS_TOL
+    c.close()
+    # an engine declared as a partition shard (here: one shard holding every partition) keeps the batch kernels
+    # for its periods, with zero-copy I/O and the completion word raised by k_post
+    c = _conv(fftSize=n_ref, max_batch=16, period=period, part_begin=0, part_end=16)
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    got3 = np.concatenate([np.stack(c.onProcess(x[0, k * period:(k + 1) * period], x[1, k * period:(k + 1) * period]))
+                           for k in range(ncalls)], axis=1)
+    assert rms(got3 - want) <= RMS_TOL
     from cuda_audio_amd._lib import McError
 
     with pytest.raises(McError):
