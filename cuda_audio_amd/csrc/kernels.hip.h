@@ -165,6 +165,25 @@ __global__ __launch_bounds__(256) void k_to_half(const float4* __restrict__ src,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = pack_half4(src[i], scale);
 }
 
+// Linear combination of up to MC_MAXV IRs (spectra as float4, taps as float2 viewed as float): dst = sum_j c_j src_j,
+// each source read only below its own length.  Used when more IRs are cross-fading than there are voices: the
+// reference's live spectrum is sum_j c_j H_j, and every deselected c_j decays by the same factor per block
+// (f_interpolate, conv.cu:27), so the deselected IRs can be merged into one.
+struct MixSrc {
+    const float* p[MC_MAXV];
+    size_t n[MC_MAXV];  // floats valid in p[j]
+    float c[MC_MAXV];
+};
+__global__ __launch_bounds__(256) void k_mix(float* __restrict__ dst, size_t n, MixSrc src) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < MC_MAXV; j++)
+            if (src.p[j] && i < src.n[j]) a = fmaf(src.c[j], src.p[j][i], a);
+        dst[i] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // complex multiply-accumulate helpers.  PACKED handles bin 0, whose float2
 // holds two independent real bins {DC, Nyquist}.

@@ -41,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int kMaxIrs = 256;
+constexpr int kMixIrs = 4;  // merged spectra of deselected IRs: [half][buffer], table entries kMaxIrs ..
 constexpr int kStageBufs = 4;
 constexpr int kEvPool = 1024;
 constexpr int kPipe = 2;
@@ -75,7 +76,8 @@ struct mc_engine {
     int stream_threshold = 0;
     int pm = 1;  // blocks per reference call (JACK period / 256): 1, 2 or 4
     int stream_nt = 256;
-    IrEntry irs[kMaxIrs];
+    IrEntry irs[kMaxIrs + kMixIrs];
+    int mix_buf[2] = {0, 0};  // which of its two merged-IR entries half i used last
     int nirs = 0;
 
     uint2* d_fdl16 = nullptr;  // fp16 mirror of the delay line (precision = fp16)
@@ -225,38 +227,94 @@ int zero_state(mc_engine* e) {
     return MC_OK;
 }
 
+int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
+
+// More IRs are cross-fading in half i than there are voices.  The reference's live spectrum is sum_j c_j H_j and
+// every deselected coefficient decays by the same factor per block (f_interpolate, conv.cu:27), so all of the
+// half's current IRs - the one being deselected included - merge into ONE spectrum M = sum_j c_j H_j that carries
+// on with coefficient 1.  The blocks played so far were weighted IR by IR: everything they still owe is rendered
+// into the residual rings first (as for a predelay change), the live pipeline restarts from silence, and the
+// half's voices become {M} plus free slots.
+int consolidate_voices(mc_engine* e, int i) {
+    int rc = retire_epoch(e, e->cur_delay, true);
+    if (rc) return rc;
+    mc_engine::VoiceSlot* vs = e->voice[i];
+    const int buf = 1 - e->mix_buf[i];
+    const int midx = kMaxIrs + i * 2 + buf;
+    IrEntry& M = e->irs[midx];
+    const size_t nH = (size_t)MC_NB * e->Pstride * 4, nh_cap = (size_t)e->cfg.n_ref * 2;
+    if (!M.d_H) HIP_TRY(hipMalloc(&M.d_H, sizeof(float) * nH));
+    if (!M.d_h) HIP_TRY(hipMalloc(&M.d_h, sizeof(float) * nh_cap));
+    MixSrc sH, sh;
+    std::memset(&sH, 0, sizeof(sH));
+    std::memset(&sh, 0, sizeof(sh));
+    double sums[4] = {0, 0, 0, 0}, bound16 = 0.0;
+    uint64_t taps = 1;
+    int P = 1;
+    for (int v = 0; v < MC_MAXV; v++) {
+        if (vs[v].ir < 0 || vs[v].coef == 0.0 || !e->irs[vs[v].ir].d_H) continue;
+        const IrEntry& src = e->irs[vs[v].ir];
+        sH.p[v] = reinterpret_cast<const float*>(src.d_H);
+        sH.n[v] = nH;
+        sH.c[v] = (float)vs[v].coef;
+        sh.p[v] = reinterpret_cast<const float*>(src.d_h);
+        sh.n[v] = (size_t)src.taps * 2;
+        sh.c[v] = (float)vs[v].coef;
+        for (int c = 0; c < 4; c++) sums[c] += vs[v].coef * src.sums[c];
+        taps = std::max(taps, src.taps);
+        P = std::max(P, src.P);
+        bound16 += std::fabs(vs[v].coef) * 16384.0 / (double)src.scale16;  // |H_j| < 2^14 / scale16_j
+    }
+    hipLaunchKernelGGL(k_mix, dim3(2048), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_H), nH, sH);
+    hipLaunchKernelGGL(k_mix, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_h), (size_t)taps * 2, sh);
+    HIP_TRY(hipGetLastError());
+    std::memcpy(M.sums, sums, sizeof(sums));
+    M.taps = taps;
+    M.P = P;
+    if (e->half) {
+        int ex = 0;
+        if (bound16 > 0.0) std::frexp(bound16, &ex);
+        M.scale16 = std::ldexp(1.0f, 13 - ex);
+        if (!M.d_H16) HIP_TRY(hipMalloc(&M.d_H16, sizeof(uint2) * (nH / 4)));
+        hipLaunchKernelGGL(k_to_half, dim3(1024), dim3(256), 0, e->stream, M.d_H, M.d_H16, nH / 4, M.scale16);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int v = 0; v < MC_MAXV; v++) vs[v] = mc_engine::VoiceSlot();
+    vs[0].ir = midx;
+    vs[0].coef = 1.0;
+    e->mix_buf[i] = buf;
+    return MC_OK;
+}
+
 // voice slot of half i that holds IR `ir`; allocates a free (fully retired) slot when it is new
-int voice_slot_for(mc_engine* e, int i, int ir, uint64_t block) {
+int voice_slot_for(mc_engine* e, int i, int ir, uint64_t block, int* err) {
     mc_engine::VoiceSlot* vs = e->voice[i];
     for (int v = 0; v < MC_MAXV; v++)
         if (vs[v].ir == ir) return v;
-    // a slot may be reused once its last non-zero gain has left every window (longest IR = Pcap blocks)
-    for (int v = 0; v < MC_MAXV; v++)
-        if (vs[v].ir < 0 || (vs[v].coef == 0.0 && (!vs[v].ever || vs[v].last_nz + (uint64_t)e->Pcap + 1 < block))) {
-            vs[v] = mc_engine::VoiceSlot();
-            vs[v].ir = ir;
-            return v;
+    for (int pass = 0; pass < 2; pass++) {
+        // a slot may be reused once its last non-zero gain has left every window (longest IR = Pcap blocks)
+        for (int v = 0; v < MC_MAXV; v++)
+            if (vs[v].ir < 0 || (vs[v].coef == 0.0 && (!vs[v].ever || vs[v].last_nz + (uint64_t)e->Pcap + 1 < block))) {
+                vs[v] = mc_engine::VoiceSlot();
+                vs[v].ir = ir;
+                return v;
+            }
+        if (pass == 0) {
+            const int rc = consolidate_voices(e, i);
+            if (rc) {
+                *err = rc;
+                return 0;
+            }
         }
-    // more than MC_MAXV IRs sounding within one IR length: the quietest one is cut off (documented limit).
-    // Its rows of the gain tables are cleared so that its old slots can never be played through the new IR.
-    int q = 0;
-    for (int v = 1; v < MC_MAXV; v++)
-        if (std::fabs(vs[v].coef) < std::fabs(vs[q].coef)) q = v;
-    const int other = e->voice[1 - i][q].ir;
-    if (other < 0 || e->voice[1 - i][q].coef == 0.0) {
-        (void)hipMemsetAsync(e->d_slotgain + (size_t)q * e->ring, 0, sizeof(float4) * (size_t)e->ring, e->stream);
-        (void)hipMemsetAsync(e->d_gring + (size_t)q * e->rc, 0, sizeof(float4) * (size_t)e->rc, e->stream);
-        e->voice_ever[q] = false;
     }
-    vs[q] = mc_engine::VoiceSlot();
-    vs[q].ir = ir;
-    return q;
+    *err = fail(MC_ERR_STATE, "no voice slot");
+    return 0;
 }
 
 // Build the per-block parameter table for T blocks starting at block e->t_front (host, double).
 // Advances the cross-fade coefficients exactly like f_interpolate + vsteps-- (conv.cu:27, 339-353).
 // Returns pstride (0 = one entry serves all blocks).
-int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_tab, int* out_n) {
+int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_tab, int* out_n, int* err) {
     BlockParams* tab = e->h_ptab[e->ptab_next];
     bool all_same = true;
     for (int t = 0; t < T; t++) {
@@ -267,7 +325,7 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
             // repeat block 0 - one table entry serves all, whatever the batch length
             bool settled = true;
             for (int i = 0; i < 2; i++) {
-                const int sv = voice_slot_for(e, i, (int)cc[i].select, blk);
+                const int sv = voice_slot_for(e, i, (int)cc[i].select, blk, err);
                 for (int v = 0; v < MC_MAXV; v++) {
                     const mc_engine::VoiceSlot& s = e->voice[i][v];
                     if (s.ir >= 0 && s.coef != ((v == sv) ? (double)cc[i].wet : 0.0)) settled = false;
@@ -292,7 +350,8 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
         for (int i = 0; i < 2 && (blk % (uint64_t)e->pm) == 0; i++) {
             const double wet = (double)cc[i].wet;
             const double div = (double)(cc[i].vsteps + 5);
-            const int sv = voice_slot_for(e, i, (int)cc[i].select, blk);
+            const int sv = voice_slot_for(e, i, (int)cc[i].select, blk, err);
+            if (*err) return 0;
             for (int v = 0; v < MC_MAXV; v++) {
                 mc_engine::VoiceSlot& s = e->voice[i][v];
                 if (s.ir < 0) continue;
@@ -422,7 +481,9 @@ int stage_params(mc_engine* e, int T, mc_cc_value (&cc)[2], Staged* st) {
     int ntab;
     // reuse of a pinned staging buffer: wait until its previous upload has run
     if (e->ptab_ev_used[e->ptab_next]) HIP_TRY(hipEventSynchronize(e->ptab_ev[e->ptab_next]));
-    const int pstride = build_params(e, T, cc, &tab, &ntab);
+    int berr = MC_OK;
+    const int pstride = build_params(e, T, cc, &tab, &ntab, &berr);
+    if (berr) return berr;
     {
         // vsteps counts down on the engine's copy too (conv.cu:345,353)
         std::lock_guard<std::mutex> lk(e->pmu);
@@ -614,14 +675,14 @@ int zero_ring_range(mc_engine* e, float* ring, uint64_t from, uint64_t to) {
 // by the predelay current at that call (conv.cu:411-415), so the blocks played so far keep their old offset:
 // render what they still owe (partition sums over silent input, Q1/Q2 window terms, Q8 drops) into the
 // residual rings and restart the live pipeline from silence under the new predelay.
-int retire_epoch(mc_engine* e, uint64_t new_delay) {
-    if (new_delay == e->cur_delay) return MC_OK;
+int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
+    if (new_delay == e->cur_delay && !force) return MC_OK;
     if (e->t_front == e->epoch_b0) {  // nothing has been played under the old value
         e->cur_delay = new_delay;
         return MC_OK;
     }
-    if (e->pipe_count) return fail(MC_ERR_STATE, "predelay changed while a batch awaits mc_finish_batch_device");
-    if (e->sliced) return fail(MC_ERR_STATE, "predelay changed on a block-sliced engine (mc_reset first)");
+    if (e->pipe_count) return fail(MC_ERR_STATE, "predelay change / voice merge while a batch awaits mc_finish_batch_device");
+    if (e->sliced) return fail(MC_ERR_STATE, "predelay change / voice merge on a block-sliced engine (mc_reset first)");
     const uint64_t b0 = e->t_front, bs = e->epoch_b0, d_old = e->cur_delay;
     // the latest old call started at block b0 - pm; the reference cuts its contribution n_ref samples later
     const uint64_t new_end = (b0 - (uint64_t)e->pm) * MC_B + e->cfg.n_ref;
@@ -1263,11 +1324,11 @@ void mc_destroy(mc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (int i = 0; i < kMaxIrs; i++)
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
-    for (int i = 0; i < kMaxIrs; i++)
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
-    for (int i = 0; i < kMaxIrs; i++)
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H16) (void)hipFree(e->irs[i].d_H16);
     (void)hipFree(e->d_fdl);
     (void)hipFree(e->d_slotgain);

@@ -1079,3 +1079,53 @@ def test_random_controller_traffic(oracle_mod, gpu_lib, seed, mode, period):
     assert np.abs(want).max() < 1.5
     err = rms(got - want)
     assert err <= RMS_TOL, f"seed {seed}: rms {err:.3e} (signal {rms(want):.3e})"
+
+
+@pytest.mark.parametrize("mode", ["jack", "batch"])
+def test_more_irs_crossfading_than_voices(oracle_mod, gpu_lib, mode):
+    """A select controller swept across seven IRs faster than any of them can fade out (speed 100 calls): the
+    reference blends all of them in its live spectra.  The engine has three voices per half; when a fourth IR
+    arrives it renders what the blocks played so far still owe, merges the half's deselected IRs into one spectrum
+    (they all decay by the same factor from then on) and carries on - still the reference's output."""
+    import ctypes as C
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 260, 8192
+    x = make_input(nb * 256)
+    irs = [make_ir(3000 + 450 * j, seed=60 + j, norm=0.05) for j in range(7)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=16)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    cmap = (21, 22, 23, 24, 25, 26, 27, 28)
+    arr = (C.c_uint8 * 8)(*cmap)
+    # speed 100 on both halves; half 0 sweeps up through the IRs every 5 calls and back, half 1 hops around;
+    # a predelay and a wet change in between
+    events = {0: [(0, 25, 13), (1, 25, 13), (0, 22, 5)]}
+    for k, sel in enumerate([1, 2, 3, 4, 5, 6, 5, 4, 3, 2, 1, 0]):
+        events.setdefault(10 + 5 * k, []).append((0, 21, int(np.ceil(sel * 128 / 7))))
+    for k, sel in enumerate([3, 6, 1, 4, 0, 5, 2]):
+        events.setdefault(20 + 9 * k, []).append((1, 21, int(np.ceil(sel * 128 / 7))))
+    events.setdefault(57, []).append((0, 22, 40))
+    events.setdefault(90, []).append((1, 24, 100))
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    q = 0
+    while q < nb:
+        for half, ctl, val in events.get(q, []):
+            oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
+            assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
+        n = 1 if mode == "jack" else min(16, min([e for e in events if e > q] + [nb]) - q)
+        s = slice(q * 256, (q + n) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        if mode == "jack":
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        q += n
+    c.close()
+    assert ref.cc(0).select == 0 and ref.cc(1).select == 2
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
