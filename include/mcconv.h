@@ -131,7 +131,8 @@ int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2
  * same distance before the next call's slice); the partition sums and inverse transforms run over the slice plus
  * the <= 33 blocks before it that the overlap-add and the predelay reach back to (count + reach-back <=
  * max_batch).  Consequences: `first` must be the same in every call, and an engine that has been called with a
- * proper slice accepts only sliced calls and no predelay change until mc_reset (MC_ERR_STATE otherwise).
+ * proper slice accepts only sliced calls, no predelay change and at most three IRs cross-fading per half until
+ * mc_reset (MC_ERR_STATE otherwise).
  * first = 0, count = nblocks is mc_process_batch_device. */
 int mc_process_batch_slice_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
                                   uint64_t nblocks, uint64_t first, uint64_t count);
@@ -139,8 +140,9 @@ int mc_process_batch_slice_device(mc_engine *e, const float *d_in1, const float 
  * 2*nblocks*256 floats ([L | R], overlap-added and already shifted by the predelay);
  * after the caller has summed the partials of all shards (RCCL reduce / all-reduce),
  * mc_finish_batch_device applies Q1/Q2 terms, Q8, clamp and dry mix.  Every shard must
- * see the same input and parameters.  A predelay change must not arrive while a batch
- * is between its partial and its finish (MC_ERR_STATE).
+ * see the same input and parameters.  A predelay change, or a select that makes a fourth
+ * IR cross-fade in one half, re-renders the engine's history and must not arrive while a
+ * batch is between its partial and its finish (MC_ERR_STATE).
  * Up to two batches may be between their partial and their finish (finishes
  * retire batches in order), so the reduce of batch k can overlap the MAC of
  * batch k+1.  A rank that does not need the output (non-root of a reduce)
