@@ -1025,11 +1025,13 @@ def test_block_sliced_engines_tile_the_output(oracle_mod, gpu_lib, n_ref, taps, 
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("mode,period", [("jack", 256), ("batch", 256), ("jack", 512)], ids=["jack", "batch", "jack512"])
-def test_random_controller_traffic(oracle_mod, gpu_lib, seed, mode, period):
+@pytest.mark.parametrize("mode,period,nirs", [("jack", 256, 3), ("batch", 256, 3), ("jack", 512, 3), ("jack", 256, 6),
+                                              ("batch", 256, 6), ("jack", 1024, 6)],
+                         ids=["jack", "batch", "jack512", "jack_6irs", "batch_6irs", "jack1024_6irs"])
+def test_random_controller_traffic(oracle_mod, gpu_lib, seed, mode, period, nirs):
     """Randomised live control: every few calls a random controller message (select, predelay, dry, wet, speed, pans,
-    level) on a random half, applied to the restatement and to the engine through handleCC.  Three IRs, so the
-    engine's three voices can hold every IR that is still sounding."""
+    level) on a random half, applied to the restatement and to the engine through handleCC.  With three IRs the
+    engine's three voices hold every IR that is still sounding; with six they overflow and merge."""
     import ctypes as C
 
     from cuda_audio_amd.synth import make_input, make_ir
@@ -1039,7 +1041,8 @@ def test_random_controller_traffic(oracle_mod, gpu_lib, seed, mode, period):
     ncalls, n_ref = 260 // pm, 4096
     nb = ncalls * pm
     x = make_input(nb * 256)
-    irs = [make_ir(2500, seed=11, norm=0.05), make_ir(3072, seed=22, norm=0.05), make_ir(1800, seed=33, norm=0.05)]
+    irs = [make_ir(2500, seed=11, norm=0.05), make_ir(3072, seed=22, norm=0.05), make_ir(1800, seed=33, norm=0.05),
+           make_ir(2900, seed=44, norm=0.05), make_ir(900, seed=55, norm=0.05), make_ir(2200, seed=66, norm=0.05)][:nirs]
     ref = oracle_mod.RefCompat(n_ref, True)
     c = _conv(fftSize=n_ref, max_batch=16 * pm, period=period)
     for i, ir in enumerate(irs):
