@@ -72,6 +72,7 @@ struct mc_engine {
     mc_config cfg;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    int Tcap = 0;  // blocks the scratch buffers and rings are sized for: >= Tmax, and enough to re-render history in few launches
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
     int stream_threshold = 0;
     int pm = 1;  // blocks per reference call (JACK period / 256): 1, 2 or 4
@@ -596,7 +597,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         // short batches: split the partition range so that the launch has ~2048 workgroups
         const int tiles = (T + 255) / 256;
         const int psplit = std::max(1, std::min(8, 8 / tiles));
-        const int tcap = psplit > 1 ? tiles * 256 : e->Tmax;  // plane stride of Y (planes summed by k_inv)
+        const int tcap = psplit > 1 ? tiles * 256 : e->Tcap;  // plane stride of Y (planes summed by k_inv)
         int launched = 0;
         for (int a = 0; a < nact; a++) {
             const ActiveVoice& av = act[a];
@@ -703,7 +704,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
                            (int64_t)(b0 * MC_B), (int64_t)d_old, e->d_res_mac, e->rr, (int64_t)new_end);
     uint64_t tv = b0;
     while (F > 0) {
-        int Tc = std::min(F, e->Tmax);
+        int Tc = std::min(F, e->Tcap);
         if (!(Tc >= e->stream_threshold && !e->half)) Tc = std::min(Tc, e->Tstream);
         const int slot0 = (int)(tv & (uint64_t)(e->ring - 1)), seg0 = (int)(tv & (uint64_t)(e->sr - 1));
         // silent blocks into the delay line (n_frames = 0: the inputs are never read)
@@ -767,7 +768,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     if (slice) {
         halo = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
         halo = (int)std::min<uint64_t>((uint64_t)halo, e->t_front + (uint64_t)first);  // the stream starts at block 0
-        if (count + halo > e->Tmax) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds max_batch %d", count, halo, e->Tmax);
+        if (count + halo > e->Tcap) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds the capacity of %d", count, halo, e->Tcap);
         if (e->sliced && e->slice_first != first) return fail(MC_ERR_STATE, "the slice start moved from block %d to %d (mc_reset first)", e->slice_first, first);
         e->sliced = true;
         e->slice_first = first;
@@ -1232,10 +1233,11 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     mc_default_params(&e->cc[1]);
     std::memset(&e->ks, 0, sizeof(e->ks));
     e->Tmax = (int)cfg->max_batch;
+    e->Tcap = std::max(e->Tmax, 256);
     e->Pcap = cfg->max_partitions ? (int)cfg->max_partitions : (int)((cfg->n_ref - 1024 + MC_B - 1) / MC_B);
     e->Pstride = (int)next_pow2((uint64_t)round_up(e->Pcap, 16));
-    e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tmax + 64);  // + reach-back of a block slice (<= 33)
-    e->sr = (int)next_pow2((uint64_t)e->Tmax + 4);  // power of two: ring indices are masks in the kernels; a slice + reach-back <= Tmax
+    e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tcap + 64);  // + reach-back of a block slice (<= 33)
+    e->sr = (int)next_pow2((uint64_t)e->Tcap + 4);  // power of two: ring indices are masks in the kernels; a slice + reach-back <= Tmax
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
     e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
@@ -1255,7 +1257,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     e->half = cfg->precision == 1;
     if (e->half) e->stream_threshold = e->Tmax + 1;  // the fp16 MAC is the streaming sweep
-    e->Tstream = std::min(e->Tmax, std::max(1, e->stream_threshold - 1));
+    e->Tstream = std::min(e->half ? e->Tmax : e->Tcap, std::max(1, e->stream_threshold - 1));
 
 #define ENG_TRY(expr)                                                                                     \
     do {                                                                                                  \
@@ -1272,7 +1274,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
-    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * std::max(e->Tmax, 2048)));  // >= 8 planes of 256 blocks
+    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * std::max(e->Tcap, 2048)));  // >= 8 planes of 256 blocks
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
@@ -1642,7 +1644,7 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
             cap = sizeof(float4) * (uint64_t)MC_NB * e->Pstride;
             break;
         case 1: src = (const char*)e->d_fdl; cap = sizeof(float4) * (uint64_t)MC_NB * e->ring; break;
-        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * std::max(e->Tmax, 2048); break;
+        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * std::max(e->Tcap, 2048); break;
         case 3: src = (const char*)e->d_seg; cap = sizeof(float) * (uint64_t)e->sr * 2 * FFT_N; break;
         case 4: src = (const char*)e->d_wet; cap = sizeof(float) * 2 * (uint64_t)e->wr; break;
         case 5: src = (const char*)e->d_cring; cap = sizeof(double) * 4 * (uint64_t)e->rc; break;

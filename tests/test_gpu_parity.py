@@ -1132,3 +1132,44 @@ def test_more_irs_crossfading_than_voices(oracle_mod, gpu_lib, mode):
     assert ref.cc(0).select == 0 and ref.cc(1).select == 2
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+@pytest.mark.parametrize("max_batch", [256, 4])
+def test_predelay_change_and_voice_merge_at_headline_size(oracle_mod, gpu_lib, max_batch):
+    """Config-3 size (10 s IRs, P = 1723, N_ref = 524288): predelay changes and a fourth cross-fading IR while
+    audio runs, one period per call, against the single-FFT restatement.  The history is re-rendered in launches
+    of at least 256 blocks whatever max_batch is (1.3 ms per change here)."""
+    import time
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 44, 524288
+    x = make_input(nb * 256)
+    irs = [make_ir(441000, seed=5678 + j, norm=0.02) for j in range(4)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=max_batch)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    for half in (0, 1):
+        ref.set(half, speed=100, vsteps=0, select=half)
+        c.cc[half].value.update(speed=100, vsteps=0, select=half)
+    events = {8: dict(predelay=3000), 14: dict(select=2, vsteps=100), 20: dict(select=3, vsteps=100), 26: dict(predelay=0),
+              32: dict(select=1, vsteps=100)}  # half 0: IRs 0, 2, 3 sounding -> IR 1 is the fourth
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    worst = 0.0
+    for b in range(nb):
+        if b in events:
+            ref.set(0, **events[b])
+            c.cc[0].value.update(**events[b])
+        s = slice(b * 256, (b + 1) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        t0 = time.perf_counter()
+        got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        if b in events:
+            worst = max(worst, time.perf_counter() - t0)
+    c.close()
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    print(f"longest call with a re-render (max_batch {max_batch}): {worst * 1e3:.2f} ms")
