@@ -756,20 +756,22 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     if (slice && e->res_end > e->t_front * MC_B) return fail(MC_ERR_STATE, "block-sliced call while a retired predelay epoch is ringing out");
     if (!slice && e->sliced) return fail(MC_ERR_STATE, "whole-batch call on a block-sliced engine (mc_reset first)");
     Staged st;
+    int halo = 0;  // blocks before the slice that the predelay and the overlap-add reach back to
     {
         mc_cc_value cc[2];
         int rc = sample_params(e, cc);
-        if (!rc) rc = retire_epoch(e, cc[0].predelay);
+        if (rc) return rc;
+        if (slice) {  // checked before any state advances
+            halo = (int)((cc[0].predelay + MC_B - 1) / MC_B) + 1;
+            halo = (int)std::min<uint64_t>((uint64_t)halo, e->t_front + (uint64_t)first);  // the stream starts at block 0
+            if (count + halo > e->Tcap) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds the capacity of %d", count, halo, e->Tcap);
+            if (e->sliced && e->slice_first != first) return fail(MC_ERR_STATE, "the slice start moved from block %d to %d (mc_reset first)", e->slice_first, first);
+        }
+        rc = retire_epoch(e, cc[0].predelay);
         if (!rc) rc = stage_params(e, T, cc, &st);
         if (rc) return rc;
     }
-    // window of blocks to run the MAC / inverse over: the slice plus what the predelay and the overlap-add reach back to
-    int halo = 0;
     if (slice) {
-        halo = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
-        halo = (int)std::min<uint64_t>((uint64_t)halo, e->t_front + (uint64_t)first);  // the stream starts at block 0
-        if (count + halo > e->Tcap) return fail(MC_ERR_ARG, "slice of %d blocks + %d blocks of reach-back exceeds the capacity of %d", count, halo, e->Tcap);
-        if (e->sliced && e->slice_first != first) return fail(MC_ERR_STATE, "the slice start moved from block %d to %d (mc_reset first)", e->slice_first, first);
         e->sliced = true;
         e->slice_first = first;
     }
@@ -795,7 +797,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
 
-    // K1: all T blocks
+    // K1: the blocks this engine can reach (all T unless block-sliced)
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
                        e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0);
