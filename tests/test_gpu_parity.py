@@ -1173,3 +1173,45 @@ def test_predelay_change_and_voice_merge_at_headline_size(oracle_mod, gpu_lib, m
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
     print(f"longest call with a re-render (max_batch {max_batch}): {worst * 1e3:.2f} ms")
+
+
+@pytest.mark.parametrize("mode", ["jack", "batch"])
+def test_fp16_storage_with_predelay_changes_and_voice_merges(oracle_mod, gpu_lib, mode):
+    """fp16 storage mode through the history re-renders: predelay changes and a select sweep over five IRs (the
+    merged spectrum gets its own fp16 copy and scale).  Bar: the fp16 tolerance of config 5."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 160, 16384
+    x = make_input(nb * 256)
+    irs = [make_ir(9000 + 1200 * j, seed=70 + j, norm=0.05) for j in range(5)]
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=16, precision="fp16")
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    for half in (0, 1):
+        ref.set(half, speed=60, vsteps=0, select=half, dry=0.0)
+        c.cc[half].value.update(speed=60, vsteps=0, select=half, dry=0.0)
+    events = {12: (0, dict(predelay=1500)), 20: (0, dict(select=2, vsteps=60)), 28: (0, dict(select=3, vsteps=60)),
+              36: (0, dict(select=4, vsteps=60)), 44: (1, dict(select=0, vsteps=60)), 52: (1, dict(select=3, vsteps=60)),
+              60: (1, dict(select=2, vsteps=60)), 90: (0, dict(predelay=64)), 120: (0, dict(select=1, vsteps=60))}
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    q = 0
+    while q < nb:
+        if q in events:
+            half, kw = events[q]
+            ref.set(half, **kw)
+            c.cc[half].value.update(**kw)
+        n = 1 if mode == "jack" else min(16, min([e for e in events if e > q] + [nb]) - q)
+        s = slice(q * 256, (q + n) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        if mode == "jack":
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        q += n
+    c.close()
+    err = rms(got - want)  # dry = 0: the output is the wet signal
+    assert err <= FP16_REL_TOL * rms(want), f"rms err {err:.3e} vs wet rms {rms(want):.3e}"
+    assert err > 1e-7
