@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     }
 }
 
+// Polyphase components of an IR's partition sequence for the fast-FIR form of the resident MAC (load time):
+// Hp[0][bin][q] = H[bin][2q], Hp[1][bin][q] = H[bin][2q+1], Hp[2] = their sum.  ph = Pstride / 2.
+__global__ __launch_bounds__(256) void k_polyphase(const float4* __restrict__ H, float4* __restrict__ Hp, int pstride) {
+    const int ph = pstride >> 1;
+    const size_t n = (size_t)MC_NB * ph;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t bin = i / ph, q = i - bin * ph;
+        const float4 a = H[bin * pstride + 2 * q], b = H[bin * pstride + 2 * q + 1];
+        Hp[i] = a;
+        Hp[n + i] = b;
+        Hp[2 * n + i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 // fp32 -> scaled fp16 copy of an IR's spectra (load time)
 __global__ __launch_bounds__(256) void k_to_half(const float4* __restrict__ src, uint2* __restrict__ dst, size_t n, float scale) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = pack_half4(src[i], scale);
@@ -316,14 +330,20 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
                                                       float4 ugain,                         // SLOTGAIN = false
                                                       const float4* __restrict__ slotgain,  // SLOTGAIN = true: [ring]
                                                       float4* __restrict__ Y, int tcap, int accumulate,
-                                                      int psplit, int pchunk) {
+                                                      int psplit, int pchunk,
+                                                      int xstride, int xphase, int xsum, int n_first) {
     // grid = 256 bins x tiles x psplit: short batches split the partition range over `psplit` workgroups
-    // (planes of Y summed by k_inv) so that the launch still fills the chip
+    // (planes of Y summed by k_inv) so that the launch still fills the chip.
+    // The kernel is a convolution along the block axis, out[n] = sum_q H[q] x[n - q], n = n_first .. n_first + T - 1,
+    // with x[m] = X[slot0 + xstride m + xphase] (+ the next slot when xsum).  Direct form: xstride 1, xphase 0,
+    // xsum 0, n_first 0, H = the IR's partitions.  Fast-FIR form (see launch_mac_batch): three launches over the
+    // even, odd and summed polyphase components with the matching polyphase IR arrays, half as many taps and
+    // outputs each.
     __shared__ float4 s_win[(SLOTGAIN ? 8 : 4) * MAC_WQ];
     const int bin = blockIdx.x & (MC_NB - 1);
     const int rest = blockIdx.x >> 8;
     const int tile = rest / psplit, split = rest - tile * psplit;
-    const int t0 = tile * 256;
+    const int t0 = tile * 256;  // first output of the tile, relative to n_first
     p_begin += split * pchunk;
     p_end = min(p_end, p_begin + pchunk);
     Y += (size_t)split * MC_NB * tcap;
@@ -347,20 +367,29 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
         const int seg = pse - ps;  // multiple of 16
         // window entry e <-> block (t0 - pse + 1 + e), e in [0, seg + 255]
         const int nwin = seg + 256;
-        const int sbase = slot0 + t0 - pse + 1;
+        const int mbase = n_first + t0 - pse + 1;  // sequence index of window entry 0
         __syncthreads();  // previous segment's readers are done
         for (int e = threadIdx.x; e < nwin + 12; e += 256) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int slot = (sbase + e) & (ring - 1);
-            if (e < nwin) x = fk[slot];
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), x2 = x;
+            const int slot = (slot0 + xstride * (mbase + e) + xphase) & (ring - 1);
+            const int slot2 = (slot + 1) & (ring - 1);
+            if (e < nwin) {
+                x = fk[slot];
+                if (xsum) x2 = fk[slot2];
+            }
             const int pos = (e & 3) * MAC_WQ + (e >> 2);
             if (SLOTGAIN) {
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < nwin) g = slotgain[slot];
-                s_win[pos] = make_float4(g.x * x.x, g.x * x.y, g.y * x.z, g.y * x.w);
-                s_win[4 * MAC_WQ + pos] = make_float4(g.z * x.x, g.z * x.y, g.w * x.z, g.w * x.w);
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g;
+                if (e < nwin) {
+                    g = slotgain[slot];
+                    if (xsum) g2 = slotgain[slot2];
+                }
+                s_win[pos] = make_float4(g.x * x.x + g2.x * x2.x, g.x * x.y + g2.x * x2.y, g.y * x.z + g2.y * x2.z,
+                                         g.y * x.w + g2.y * x2.w);
+                s_win[4 * MAC_WQ + pos] = make_float4(g.z * x.x + g2.z * x2.x, g.z * x.y + g2.z * x2.y,
+                                                      g.w * x.z + g2.w * x2.z, g.w * x.w + g2.w * x2.w);
             } else {
-                s_win[pos] = x;
+                s_win[pos] = make_float4(x.x + x2.x, x.y + x2.y, x.z + x2.z, x.w + x2.w);
             }
         }
         __syncthreads();
@@ -533,7 +562,10 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                              int T, float* __restrict__ seg, int sr, int seg0,
-                                             const float2* __restrict__ g_tw) {
+                                             const float2* __restrict__ g_tw, int64_t ffa_plane) {
+    // ffa_plane != 0: Ysrc holds the three half-rate sequences of the fast-FIR form, `ffa_plane` elements apart:
+    // A = He*Xe (index n), B = Ho*Xo (stored from sequence index -1: B[n] sits at n + 1), C = (He+Ho)*(Xe+Xo);
+    // Y[2n] = A[n] + B[n-1], Y[2n+1] = C[n] - A[n] - B[n].
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
@@ -543,7 +575,7 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) {
+        if (t < T && ffa_plane == 0) {
             const float4* src = Ysrc + (int64_t)k * sk + (int64_t)t * st;
             for (int c = 0; c < nsum; c++) {
                 float4 a = src[c * sc];
@@ -551,6 +583,21 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
                 y.y += a.y;
                 y.z += a.z;
                 y.w += a.w;
+            }
+        } else if (t < T) {
+            const int n = t >> 1;
+            const float4* pa = Ysrc + (int64_t)k * sk + (int64_t)n * st;
+            const float4* pb = pa + ffa_plane + ((t & 1) ? st : 0);
+            const float4* pc = pa + 2 * ffa_plane;
+            const float sa = (t & 1) ? -1.f : 1.f, sb = sa, scc = (t & 1) ? 1.f : 0.f;
+            for (int c = 0; c < nsum; c++) {
+                const float4 a = pa[c * sc], b = pb[c * sc];
+                float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t & 1) cc = pc[c * sc];
+                y.x += sa * a.x + sb * b.x + scc * cc.x;
+                y.y += sa * a.y + sb * b.y + scc * cc.y;
+                y.z += sa * a.z + sb * b.z + scc * cc.z;
+                y.w += sa * a.w + sb * b.w + scc * cc.w;
             }
         }
         s_tile[k][tb] = y;

@@ -58,6 +58,7 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 
 struct IrEntry {
     float4* d_H = nullptr;
+    float4* d_Hp = nullptr;  // polyphase components {even, odd, even + odd} of the partition sequence (fast-FIR MAC)
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -155,6 +156,7 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
+    bool ffa = true;      // resident MAC in 2-parallel fast-FIR form when the batch and the IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
     bool uniform_valid[2] = {false, false};
@@ -174,6 +176,8 @@ struct mc_engine {
 };
 
 namespace {
+
+size_t y_capacity(const mc_engine* e) { return std::max<size_t>(2 * (size_t)e->Tcap + 4096, 8192); }  // blocks per bin
 
 void host_twiddles(std::vector<float2>& tw) {
     tw.resize(FFT_N);
@@ -230,6 +234,16 @@ int zero_state(mc_engine* e) {
 
 int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 
+// polyphase components of an IR's spectra for the fast-FIR form of the resident MAC
+int build_polyphase(mc_engine* e, IrEntry& ir) {
+    if (e->half || e->Pstride < 64) return MC_OK;  // the fp16 MAC streams; tiny engines never use the fast form
+    const size_t n = (size_t)3 * MC_NB * (e->Pstride / 2);
+    if (!ir.d_Hp) HIP_TRY(hipMalloc(&ir.d_Hp, sizeof(float4) * n));
+    hipLaunchKernelGGL(k_polyphase, dim3(1024), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp, e->Pstride);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
 // More IRs are cross-fading in half i than there are voices.  The reference's live spectrum is sum_j c_j H_j and
 // every deselected coefficient decays by the same factor per block (f_interpolate, conv.cu:27), so all of the
 // half's current IRs - the one being deselected included - merge into ONE spectrum M = sum_j c_j H_j that carries
@@ -269,6 +283,8 @@ int consolidate_voices(mc_engine* e, int i) {
     hipLaunchKernelGGL(k_mix, dim3(2048), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_H), nH, sH);
     hipLaunchKernelGGL(k_mix, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_h), (size_t)taps * 2, sh);
     HIP_TRY(hipGetLastError());
+    rc = build_polyphase(e, M);
+    if (rc) return rc;
     std::memcpy(M.sums, sums, sizeof(sums));
     M.taps = taps;
     M.P = P;
@@ -585,6 +601,7 @@ struct MacOut {
     int nsum;
     int swept;
     bool resident;
+    int64_t ffa_plane;  // != 0: three half-rate sequences this many elements apart (k_inv combines them)
 };
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
@@ -593,6 +610,50 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     mo->resident = T >= e->stream_threshold && !e->half;
     mo->swept = 0;
     mo->sc = 1;
+    mo->ffa_plane = 0;
+    // 2-parallel fast-FIR form of the convolution along the block axis.  With the polyphase components
+    // Xe[n] = X[2n], Xo[n] = X[2n+1], He[q] = H[2q], Ho[q] = H[2q+1] (indices relative to the batch start):
+    //   Y[2n] = (He*Xe)[n] + (Ho*Xo)[n-1],   Y[2n+1] = ((He+Ho)*(Xe+Xo))[n] - (He*Xe)[n] - (Ho*Xo)[n]
+    // - three convolutions with half the taps and half the outputs each: 3/4 of the multiply-adds of the direct
+    // form.  The resident kernel runs once per component; k_inv combines them.
+    bool use_ffa = mo->resident && e->ffa && T >= 4096 && (T % 2) == 0 && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && e->Pstride >= 64;
+    for (int a = 0; a < nact && use_ffa; a++)
+        if (!act[a].ir0->d_Hp || !act[a].ir1->d_Hp || act[a].p_end < 256) use_ffa = false;
+    if (use_ffa) {
+        const int nh = T / 2, ph = e->Pstride / 2;
+        const int tiles = (nh + 1 + 255) / 256;  // the odd component starts one output early
+        const int tcap = tiles * 256;
+        const size_t plane = (size_t)MC_NB * tcap;
+        int launched = 0;
+        for (int a = 0; a < nact; a++) {
+            const ActiveVoice& av = act[a];
+            const int q_end = round_up((av.p_end + 1) / 2, 16);
+            const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
+            for (int c = 0; c < 3; c++) {  // A: even, B: odd (from output -1), C: sum
+                const int nout = c == 1 ? nh + 1 : nh;
+                const dim3 grid(MC_NB * ((nout + 255) / 256));
+                const float4* h0 = av.ir0->d_Hp + (size_t)c * MC_NB * ph;
+                const float4* h1 = av.ir1->d_Hp + (size_t)c * MC_NB * ph;
+                float4* y = e->d_Y + (size_t)c * plane;
+                const int xphase = c == 1 ? 1 : 0, xsum = c == 2 ? 1 : 0, n_first = c == 1 ? -1 : 0;
+                if (av.uniform && !per_slot_gains)
+                    hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, h0, h1, ph, 0, q_end, e->d_fdl, e->ring,
+                                       slot0, nout, av.ugain, sg, y, tcap, launched ? 1 : 0, 1, q_end, 2, xphase, xsum, n_first);
+                else
+                    hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, h0, h1, ph, 0, q_end, e->d_fdl, e->ring,
+                                       slot0, nout, av.ugain, sg, y, tcap, launched ? 1 : 0, 1, q_end, 2, xphase, xsum, n_first);
+            }
+            launched++;
+            mo->swept = std::max(mo->swept, av.p_end);
+        }
+        mo->ysrc = e->d_Y;
+        mo->sk = tcap;
+        mo->stt = 1;
+        mo->nsum = 1;
+        mo->sc = 0;
+        mo->ffa_plane = (int64_t)plane;
+        return MC_OK;
+    }
     if (mo->resident) {
         // short batches: split the partition range so that the launch has ~2048 workgroups
         const int tiles = (T + 255) / 256;
@@ -610,11 +671,11 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
             if (av.uniform && !per_slot_gains)
                 hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
                                    p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk);
+                                   psplit, pchunk, 1, 0, 0, 0);
             else
                 hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
                                    p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk);
+                                   psplit, pchunk, 1, 0, 0, 0);
             launched++;
             mo->swept = std::max(mo->swept, p_end - p_begin);
         }
@@ -716,7 +777,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
         hipLaunchKernelGGL(k_inv, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
-                           mo.sc, Tc, e->d_seg, e->sr, seg0, e->d_tw);
+                           mo.sc, Tc, e->d_seg, e->sr, seg0, e->d_tw, mo.ffa_plane);
         hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, (int64_t)tv, (int64_t)d_old,
                            e->d_res_mac, e->rr, (int64_t)new_end);
         tv += (uint64_t)Tc;
@@ -833,7 +894,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 e->ks.partitions = (uint32_t)mo.swept;
             }
             hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
-                               mo.sc, n, e->d_seg, e->sr, (int)(b & (uint64_t)(e->sr - 1)), e->d_tw);
+                               mo.sc, n, e->d_seg, e->sr, (int)(b & (uint64_t)(e->sr - 1)), e->d_tw, mo.ffa_plane);
         }
     }
     if (lin)
@@ -1276,7 +1337,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
-    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * std::max(e->Tcap, 2048)));  // >= 8 planes of 256 blocks
+    // >= 8 planes of 256 blocks; the fast-FIR form writes three half-rate sequences (1.5 x the blocks, + a tile each)
+    ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * y_capacity(e)));
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
@@ -1307,6 +1369,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
+    if (std::getenv("MCCONV_NO_FFA")) e->ffa = false;
     {
         std::vector<float2> tw;
         host_twiddles(tw);
@@ -1330,6 +1393,8 @@ void mc_destroy(mc_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
+        if (e->irs[i].d_Hp) (void)hipFree(e->irs[i].d_Hp);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
@@ -1417,6 +1482,11 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     }
     if (ir.d_h) (void)hipFree(ir.d_h);
     ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
+    {
+        int rc = build_polyphase(e, ir);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     if (e->half) {
         // scaled fp16 copy: one power-of-two scale per IR puts the largest bin near 2^13 (half max 65504);
         // a 60 dB decay then still sits ~2^3 above the smallest normal half
@@ -1646,7 +1716,7 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
             cap = sizeof(float4) * (uint64_t)MC_NB * e->Pstride;
             break;
         case 1: src = (const char*)e->d_fdl; cap = sizeof(float4) * (uint64_t)MC_NB * e->ring; break;
-        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * std::max(e->Tcap, 2048); break;
+        case 2: src = (const char*)e->d_Y; cap = sizeof(float4) * (uint64_t)MC_NB * y_capacity(e); break;
         case 3: src = (const char*)e->d_seg; cap = sizeof(float) * (uint64_t)e->sr * 2 * FFT_N; break;
         case 4: src = (const char*)e->d_wet; cap = sizeof(float) * 2 * (uint64_t)e->wr; break;
         case 5: src = (const char*)e->d_cring; cap = sizeof(double) * 4 * (uint64_t)e->rc; break;

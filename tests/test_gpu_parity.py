@@ -1215,3 +1215,54 @@ def test_fp16_storage_with_predelay_changes_and_voice_merges(oracle_mod, gpu_lib
     err = rms(got - want)  # dry = 0: the output is the wet signal
     assert err <= FP16_REL_TOL * rms(want), f"rms err {err:.3e} vs wet rms {rms(want):.3e}"
     assert err > 1e-7
+
+
+def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch):
+    """Batches of >= 4096 blocks run the resident MAC in 2-parallel fast-FIR form (three half-rate convolutions over
+    the polyphase components of the block sequence, 3/4 of the multiply-adds).  Same output as the direct form and
+    as the oracle: through the cold-start ramp (per-slot gains), for a batch that starts at an odd block, for a
+    batch length that is not a multiple of the tile, and with two voices (IR switch)."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref = 131072
+    sizes = [3, 4098, 4096]
+    nb = sum(sizes)
+    x = make_input(nb * 256)
+    irs = [make_ir(88200, seed=5678, norm=0.02), make_ir(80000, seed=5680, norm=0.02), make_ir(70000, seed=5682, norm=0.02)]
+    p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
+
+    def run(no_ffa):
+        if no_ffa:
+            monkeypatch.setenv("MCCONV_NO_FFA", "1")
+        else:
+            monkeypatch.delenv("MCCONV_NO_FFA", raising=False)
+        c = _conv(fftSize=n_ref, max_batch=4098)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        out = np.zeros((2, nb * 256), np.float32)
+        o = 0
+        for k, n in enumerate(sizes):
+            if k == 2:
+                c.cc[0].value.update(select=2, vsteps=100)  # cross-fade to a third IR during the last batch
+            s = slice(o * 256, (o + n) * 256)
+            out[:, s] = c.process(x[0, s], x[1, s])
+            o += n
+        ks = c.kernel_stats()
+        c.close()
+        return out, ks
+
+    fast, _ = run(False)
+    direct, _ = run(True)
+    assert rms(fast - direct) <= 2e-6, f"fast-FIR vs direct: {rms(fast - direct):.3e}"
+    assert rms(fast - direct) > 0  # they really are different computations
+    # oracle on the first two batches (float64 partitioned form, which models a constant select; the third batch,
+    # with the IR switch, is covered by the comparison with the direct form above)
+    nchk = sizes[0] + sizes[1]
+    o = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        o.prepare(i, ir)
+    apply_params(o, p0, p1, True)
+    want = o.process(x[0, : nchk * 256], x[1, : nchk * 256])
+    err = rms(fast[:, : nchk * 256] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
