@@ -444,10 +444,17 @@ def main():
         # its binding resource is fp32 FMA issue.  The f32 MFMA peak of gfx950 equals the vector rate (157.3 TF).
         roofline = dict({"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4)}, **common)
+        lv = int(ks.get("fast_levels", 0))
+        executed_tf = achieved_tf * (0.75 ** lv)
+        roofline["executed"] = {"fast_fir_levels": lv, "multiply_add_fraction": round(0.75 ** lv, 4),
+                                "tflops": round(executed_tf, 2), "frac": round(executed_tf / FP32_PEAK_TFLOPS, 4)}
         roofline["hbm_equivalent"] = hbm_equiv
         roofline["note"] = ("fp32 complex MAC on the vector ALU (v_pk_fma_f32; no MFMA instruction is used - the f32 MFMA rate "
-                            "of gfx950 equals the vector rate, so the peak is the same 157.3 TFLOP/s). achieved = 8 flop x 4 paths "
-                            "x partitions x 256 bins x blocks / MAC kernel time (HIP events on the launch stream). "
+                            "of gfx950 equals the vector rate, so the peak is the same 157.3 TFLOP/s). achieved = ALGORITHMIC flops "
+                            "of the partition x bin MAC, 8 flop x 4 paths x partitions x 256 bins x blocks / MAC kernel time (HIP "
+                            "events on the launch stream). The kernel runs the convolution along the block axis in fast-FIR form "
+                            "(polyphase components, `executed.fast_fir_levels` nested levels): it issues (3/4)^levels of those "
+                            "multiply-adds, so `achieved` can exceed the peak; `executed` is what the ALUs do. "
                             "traffic = HBM bytes per launch from FETCH_SIZE/WRITE_SIZE (profiles/).")
     else:
         roofline = dict({"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -66,6 +66,8 @@ class McKernelStats(C.Structure):
         ("last_ms", C.c_double),
         ("resident", C.c_uint32),
         ("partitions", C.c_uint32),
+        ("fast_levels", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -160,17 +160,41 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     }
 }
 
-// Polyphase components of an IR's partition sequence for the fast-FIR form of the resident MAC (load time):
-// Hp[0][bin][q] = H[bin][2q], Hp[1][bin][q] = H[bin][2q+1], Hp[2] = their sum.  ph = Pstride / 2.
-__global__ __launch_bounds__(256) void k_polyphase(const float4* __restrict__ H, float4* __restrict__ Hp, int pstride) {
-    const int ph = pstride >> 1;
+// Fast-FIR components.  Level L splits a sequence into 3^L sub-sequences at 1/2^L of the rate; component c has
+// base-3 digits (d_1 .. d_L, most significant first), digit 0 = even samples, 1 = odd samples, 2 = their sum.
+// In terms of the original sequence a component is the sum over a set of residues j modulo 2^L:
+//   ffa_mask(c, L) bit j set  <=>  x_c[m] includes X[2^L m + j].
+__host__ __device__ __forceinline__ int ffa_digit_mask(int d) { return d == 0 ? 1 : (d == 1 ? 2 : 3); }
+__host__ __device__ __forceinline__ int ffa_mask(int c, int lvl) {
+    if (lvl == 1) return ffa_digit_mask(c);
+    // level 2: first digit selects residues j1 in {0,1} at stride 2, second digit j2 in {0,1} at stride 4: j = 2 j2 + j1
+    const int m1 = ffa_digit_mask(c / 3), m2 = ffa_digit_mask(c % 3);
+    int m = 0;
+    for (int j2 = 0; j2 < 2; j2++)
+        for (int j1 = 0; j1 < 2; j1++)
+            if (((m2 >> j2) & 1) && ((m1 >> j1) & 1)) m |= 1 << (2 * j2 + j1);
+    return m;
+}
+
+// Components of an IR's partition sequence (load time): Hp[c][bin][q] = sum_{j in mask(c)} H[bin][2^L q + j],
+// 3^L arrays of pstride / 2^L partitions each.
+__global__ __launch_bounds__(256) void k_polyphase(const float4* __restrict__ H, float4* __restrict__ Hp, int pstride, int lvl) {
+    const int ph = pstride >> lvl, nc = lvl == 1 ? 3 : 9;
     const size_t n = (size_t)MC_NB * ph;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const size_t bin = i / ph, q = i - bin * ph;
-        const float4 a = H[bin * pstride + 2 * q], b = H[bin * pstride + 2 * q + 1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n * nc; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / n);
+        const size_t r = i - (size_t)c * n, bin = r / ph, q = r - bin * ph;
+        const int mask = ffa_mask(c, lvl);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < (1 << lvl); j++)
+            if ((mask >> j) & 1) {
+                const float4 h = H[bin * pstride + (q << lvl) + j];
+                a.x += h.x;
+                a.y += h.y;
+                a.z += h.z;
+                a.w += h.w;
+            }
         Hp[i] = a;
-        Hp[n + i] = b;
-        Hp[2 * n + i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
 }
 
@@ -330,27 +354,29 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
                                                       float4 ugain,                         // SLOTGAIN = false
                                                       const float4* __restrict__ slotgain,  // SLOTGAIN = true: [ring]
                                                       float4* __restrict__ Y, int tcap, int accumulate,
-                                                      int psplit, int pchunk,
-                                                      int xstride, int xphase, int xsum, int n_first) {
+                                                      int psplit, int pchunk, int lvl, int tiles, int64_t yplane) {
     // grid = 256 bins x tiles x psplit: short batches split the partition range over `psplit` workgroups
     // (planes of Y summed by k_inv) so that the launch still fills the chip.
-    // The kernel is a convolution along the block axis, out[n] = sum_q H[q] x[n - q], n = n_first .. n_first + T - 1,
-    // with x[m] = X[slot0 + xstride m + xphase] (+ the next slot when xsum).  Direct form: xstride 1, xphase 0,
-    // xsum 0, n_first 0, H = the IR's partitions.  Fast-FIR form (see launch_mac_batch): three launches over the
-    // even, odd and summed polyphase components with the matching polyphase IR arrays, half as many taps and
-    // outputs each.
+    // The kernel is a convolution along the block axis, out[n] = sum_q H[q] x[n - q].  lvl = 0, the direct form:
+    // x = the delay line from slot0, H = the IR's partitions, outputs n = 0 .. T-1.  lvl = 1, 2: the fast-FIR form
+    // (launch_mac_batch) - the grid also spans the 3^lvl components; component c convolves
+    // x_c[m] = sum_{j in mask(c)} X[slot0 + 2^lvl m + j] with the matching component of the IR (H0/H1 point to the
+    // component arrays, `pstride_ir` partitions each) for outputs n = -1 .. T-2, into plane c of Y.
     __shared__ float4 s_win[(SLOTGAIN ? 8 : 4) * MAC_WQ];
     const int bin = blockIdx.x & (MC_NB - 1);
-    const int rest = blockIdx.x >> 8;
+    int rest = blockIdx.x >> 8;
+    const int comp = rest / (tiles * psplit);  // 0 in the direct form
+    rest -= comp * tiles * psplit;
     const int tile = rest / psplit, split = rest - tile * psplit;
     const int t0 = tile * 256;  // first output of the tile, relative to n_first
+    const int xstride = 1 << lvl, xmask = lvl ? ffa_mask(comp, lvl) : 1, n_first = lvl ? -1 : 0;
     p_begin += split * pchunk;
     p_end = min(p_end, p_begin + pchunk);
-    Y += (size_t)split * MC_NB * tcap;
+    Y += (size_t)split * MC_NB * tcap + (size_t)comp * yplane;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float4* H0k = H0 + (size_t)bin * pstride_ir;
-    const float4* H1k = H1 + (size_t)bin * pstride_ir;
+    const float4* H0k = H0 + ((size_t)comp * MC_NB + bin) * pstride_ir;
+    const float4* H1k = H1 + ((size_t)comp * MC_NB + bin) * pstride_ir;
     const float4* fk = fdl + (size_t)bin * ring;
 
     float2 acc[4][4];   // SLOTGAIN = false: four path sums per output
@@ -370,27 +396,25 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
         const int mbase = n_first + t0 - pse + 1;  // sequence index of window entry 0
         __syncthreads();  // previous segment's readers are done
         for (int e = threadIdx.x; e < nwin + 12; e += 256) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), x2 = x;
-            const int slot = (slot0 + xstride * (mbase + e) + xphase) & (ring - 1);
-            const int slot2 = (slot + 1) & (ring - 1);
-            if (e < nwin) {
-                x = fk[slot];
-                if (xsum) x2 = fk[slot2];
-            }
+            const int sb = slot0 + xstride * (mbase + e);
             const int pos = (e & 3) * MAC_WQ + (e >> 2);
-            if (SLOTGAIN) {
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g;
-                if (e < nwin) {
-                    g = slotgain[slot];
-                    if (xsum) g2 = slotgain[slot2];
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j < xstride && ((xmask >> j) & 1) && e < nwin) {
+                    const int slot = (sb + j) & (ring - 1);
+                    const float4 x = fk[slot];
+                    if (SLOTGAIN) {
+                        const float4 g = slotgain[slot];
+                        a = make_float4(a.x + g.x * x.x, a.y + g.x * x.y, a.z + g.y * x.z, a.w + g.y * x.w);
+                        b = make_float4(b.x + g.z * x.x, b.y + g.z * x.y, b.z + g.w * x.z, b.w + g.w * x.w);
+                    } else {
+                        a = make_float4(a.x + x.x, a.y + x.y, a.z + x.z, a.w + x.w);
+                    }
                 }
-                s_win[pos] = make_float4(g.x * x.x + g2.x * x2.x, g.x * x.y + g2.x * x2.y, g.y * x.z + g2.y * x2.z,
-                                         g.y * x.w + g2.y * x2.w);
-                s_win[4 * MAC_WQ + pos] = make_float4(g.z * x.x + g2.z * x2.x, g.z * x.y + g2.z * x2.y,
-                                                      g.w * x.z + g2.w * x2.z, g.w * x.w + g2.w * x2.w);
-            } else {
-                s_win[pos] = make_float4(x.x + x2.x, x.y + x2.y, x.z + x2.z, x.w + x2.w);
             }
+            s_win[pos] = a;
+            if (SLOTGAIN) s_win[4 * MAC_WQ + pos] = b;
         }
         __syncthreads();
         const int per = seg >> 2;  // partitions per wave, multiple of 4
@@ -554,6 +578,41 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
 }
 
 // ---------------------------------------------------------------------------
+// Fast-FIR form: combine the 3^lvl component sequences the resident kernel wrote (each `plane` elements apart,
+// [bin][tcap], stored from sequence index -1: Z[n] sits at n + 1) into the partition sums of blocks 0 .. T-1,
+// Yc[bin][t].  One level, with A = even, B = odd, C = sum component:
+//   Y[2n] = A[n] + B[n-1],   Y[2n+1] = C[n] - A[n] - B[n];
+// with two levels A, B, C are themselves combined the same way from their own three components.
+// grid = (ceil(T / 256), 256 bins): consecutive threads = consecutive blocks of one bin.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ffa_combine(const float4* __restrict__ Yp, int64_t plane, int tcap, int lvl, int T,
+                                                     float4* __restrict__ Yc, int ycap) {
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (t >= T) return;
+    const float4* base = Yp + (int64_t)k * tcap + 1;  // + 1: sequences start at index -1
+    auto half_rate = [&](int d1, int n) -> float4 {    // half-rate sequence d1 (0 even, 1 odd, 2 sum) at index n
+        if (lvl == 1) return base[(int64_t)d1 * plane + n];
+        const int kq = n >> 1;  // arithmetic shift: n = -1 -> kq = -1
+        const float4* p = base + (int64_t)(3 * d1) * plane;
+        const float4 za = p[kq], zb = p[plane + kq - ((n & 1) ? 0 : 1)];
+        if ((n & 1) == 0) return make_float4(za.x + zb.x, za.y + zb.y, za.z + zb.z, za.w + zb.w);
+        const float4 zc = p[2 * plane + kq];
+        return make_float4(zc.x - za.x - zb.x, zc.y - za.y - zb.y, zc.z - za.z - zb.z, zc.w - za.w - zb.w);
+    };
+    const int n = t >> 1;
+    const float4 A = half_rate(0, n);
+    float4 y;
+    if ((t & 1) == 0) {
+        const float4 B = half_rate(1, n - 1);
+        y = make_float4(A.x + B.x, A.y + B.y, A.z + B.z, A.w + B.w);
+    } else {
+        const float4 B = half_rate(1, n), C = half_rate(2, n);
+        y = make_float4(C.x - A.x - B.x, C.y - A.y - B.y, C.z - A.z - B.z, C.w - A.w - B.w);
+    }
+    Yc[(size_t)k * ycap + t] = y;
+}
+
+// ---------------------------------------------------------------------------
 // K3: packed inverse transform.  W = Y_L + j Y_R (Hermitian-extended), one
 // 512-point inverse per block, real part = left segment, imaginary = right
 // (replaces the two cufftExecC2C inverse calls, conv.cu:403-408).
@@ -562,10 +621,7 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                              int T, float* __restrict__ seg, int sr, int seg0,
-                                             const float2* __restrict__ g_tw, int64_t ffa_plane) {
-    // ffa_plane != 0: Ysrc holds the three half-rate sequences of the fast-FIR form, `ffa_plane` elements apart:
-    // A = He*Xe (index n), B = Ho*Xo (stored from sequence index -1: B[n] sits at n + 1), C = (He+Ho)*(Xe+Xo);
-    // Y[2n] = A[n] + B[n-1], Y[2n+1] = C[n] - A[n] - B[n].
+                                             const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[4][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
@@ -575,7 +631,7 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T && ffa_plane == 0) {
+        if (t < T) {
             const float4* src = Ysrc + (int64_t)k * sk + (int64_t)t * st;
             for (int c = 0; c < nsum; c++) {
                 float4 a = src[c * sc];
@@ -583,21 +639,6 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
                 y.y += a.y;
                 y.z += a.z;
                 y.w += a.w;
-            }
-        } else if (t < T) {
-            const int n = t >> 1;
-            const float4* pa = Ysrc + (int64_t)k * sk + (int64_t)n * st;
-            const float4* pb = pa + ffa_plane + ((t & 1) ? st : 0);
-            const float4* pc = pa + 2 * ffa_plane;
-            const float sa = (t & 1) ? -1.f : 1.f, sb = sa, scc = (t & 1) ? 1.f : 0.f;
-            for (int c = 0; c < nsum; c++) {
-                const float4 a = pa[c * sc], b = pb[c * sc];
-                float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t & 1) cc = pc[c * sc];
-                y.x += sa * a.x + sb * b.x + scc * cc.x;
-                y.y += sa * a.y + sb * b.y + scc * cc.y;
-                y.z += sa * a.z + sb * b.z + scc * cc.z;
-                y.w += sa * a.w + sb * b.w + scc * cc.w;
             }
         }
         s_tile[k][tb] = y;

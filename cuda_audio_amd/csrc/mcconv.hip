@@ -58,7 +58,7 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 
 struct IrEntry {
     float4* d_H = nullptr;
-    float4* d_Hp = nullptr;  // polyphase components {even, odd, even + odd} of the partition sequence (fast-FIR MAC)
+    float4* d_Hp[2] = {nullptr, nullptr};  // fast-FIR components of the partition sequence: level 1 (3 arrays), level 2 (9)
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -84,6 +84,7 @@ struct mc_engine {
 
     uint2* d_fdl16 = nullptr;  // fp16 mirror of the delay line (precision = fp16)
     bool half = false;
+    float4* d_Yc = nullptr;  // [256][Tcap] partition sums combined from the fast-FIR components
     float4 *d_fdl = nullptr, *d_slotgain = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
     float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
@@ -156,7 +157,7 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
-    bool ffa = true;      // resident MAC in 2-parallel fast-FIR form when the batch and the IR are long enough
+    int ffa_levels = 2;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
     bool uniform_valid[2] = {false, false};
@@ -177,7 +178,7 @@ struct mc_engine {
 
 namespace {
 
-size_t y_capacity(const mc_engine* e) { return std::max<size_t>(2 * (size_t)e->Tcap + 4096, 8192); }  // blocks per bin
+size_t y_capacity(const mc_engine* e) { return std::max<size_t>(9 * ((size_t)e->Tcap / 4 + 256) + 1024, 8192); }  // blocks per bin
 
 void host_twiddles(std::vector<float2>& tw) {
     tw.resize(FFT_N);
@@ -234,12 +235,14 @@ int zero_state(mc_engine* e) {
 
 int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 
-// polyphase components of an IR's spectra for the fast-FIR form of the resident MAC
+// fast-FIR components of an IR's spectra (levels 1 and 2) for the resident MAC
 int build_polyphase(mc_engine* e, IrEntry& ir) {
-    if (e->half || e->Pstride < 64) return MC_OK;  // the fp16 MAC streams; tiny engines never use the fast form
-    const size_t n = (size_t)3 * MC_NB * (e->Pstride / 2);
-    if (!ir.d_Hp) HIP_TRY(hipMalloc(&ir.d_Hp, sizeof(float4) * n));
-    hipLaunchKernelGGL(k_polyphase, dim3(1024), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp, e->Pstride);
+    if (e->half || e->Pstride < 128) return MC_OK;  // the fp16 MAC streams; small engines never use the fast form
+    for (int lvl = 1; lvl <= 2; lvl++) {
+        const size_t n = (size_t)(lvl == 1 ? 3 : 9) * MC_NB * (e->Pstride >> lvl);
+        if (!ir.d_Hp[lvl - 1]) HIP_TRY(hipMalloc(&ir.d_Hp[lvl - 1], sizeof(float4) * n));
+        hipLaunchKernelGGL(k_polyphase, dim3(2048), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp[lvl - 1], e->Pstride, lvl);
+    }
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }
@@ -601,8 +604,31 @@ struct MacOut {
     int nsum;
     int swept;
     bool resident;
-    int64_t ffa_plane;  // != 0: three half-rate sequences this many elements apart (k_inv combines them)
+    int lvl;            // fast-FIR levels of the main part (0 = direct form)
+    int64_t ffa_plane;  // elements between the component sequences (k_inv combines them)
+    int main_n;         // blocks described by the fields above; the remaining tail_n blocks of the batch come from
+    int tail_n;         // the streaming kernel:
+    const float4* tail_ysrc;
+    int64_t tail_sk, tail_stt;
+    int tail_nsum;
 };
+
+// inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0`
+void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0) {
+    if (mo.main_n > 0 && mo.lvl) {
+        hipLaunchKernelGGL(k_ffa_combine, dim3((mo.main_n + 255) / 256, MC_NB), dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane,
+                           (int)mo.sk, mo.lvl, mo.main_n, e->d_Yc, e->Tcap);
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, e->d_Yc, (int64_t)e->Tcap,
+                           (int64_t)1, 1, (int64_t)0, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
+    } else if (mo.main_n > 0) {
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
+                           mo.sc, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
+    }
+    if (mo.tail_n > 0)
+        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.tail_ysrc, mo.tail_sk,
+                           mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, e->d_seg, e->sr,
+                           (int)((b0 + (uint64_t)mo.main_n) & (uint64_t)(e->sr - 1)), e->d_tw);
+}
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
 // per_slot_gains: the batch's blocks (or the window) do not share one set of gains.
@@ -610,39 +636,49 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     mo->resident = T >= e->stream_threshold && !e->half;
     mo->swept = 0;
     mo->sc = 1;
+    mo->lvl = 0;
     mo->ffa_plane = 0;
-    // 2-parallel fast-FIR form of the convolution along the block axis.  With the polyphase components
-    // Xe[n] = X[2n], Xo[n] = X[2n+1], He[q] = H[2q], Ho[q] = H[2q+1] (indices relative to the batch start):
+    mo->main_n = T;
+    mo->tail_n = 0;
+    // Fast-FIR form of the convolution along the block axis.  With the polyphase components Xe[n] = X[2n],
+    // Xo[n] = X[2n+1], He[q] = H[2q], Ho[q] = H[2q+1] (indices relative to the batch start):
     //   Y[2n] = (He*Xe)[n] + (Ho*Xo)[n-1],   Y[2n+1] = ((He+Ho)*(Xe+Xo))[n] - (He*Xe)[n] - (Ho*Xo)[n]
-    // - three convolutions with half the taps and half the outputs each: 3/4 of the multiply-adds of the direct
-    // form.  The resident kernel runs once per component; k_inv combines them.
-    bool use_ffa = mo->resident && e->ffa && T >= 4096 && (T % 2) == 0 && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && e->Pstride >= 64;
-    for (int a = 0; a < nact && use_ffa; a++)
-        if (!act[a].ir0->d_Hp || !act[a].ir1->d_Hp || act[a].p_end < 256) use_ffa = false;
-    if (use_ffa) {
-        const int nh = T / 2, ph = e->Pstride / 2;
-        const int tiles = (nh + 1 + 255) / 256;  // the odd component starts one output early
+    // - three convolutions with half the taps and half the outputs: 3/4 of the multiply-adds; applied to each of
+    // the three again (level 2): nine convolutions at a quarter of the rate, 9/16.  One launch of the resident
+    // kernel covers all components; k_inv combines them.  Every component is computed for sequence indices
+    // -1 .. T/2^L - 2, which covers the first T - 2^L blocks of the batch; the last 2^L blocks go through the
+    // streaming kernel, so that no tile is spent on one extra output.
+    int lvl = 0;
+    if (mo->resident && e->ffa_levels > 0 && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0) {
+        int pmin = 1 << 30;
+        bool have = true;
+        for (int a = 0; a < nact; a++) {
+            pmin = std::min(pmin, act[a].p_end);
+            have = have && act[a].ir0->d_Hp[0] && act[a].ir1->d_Hp[0] && act[a].ir0->d_Hp[1] && act[a].ir1->d_Hp[1];
+        }
+        if (have && e->ffa_levels >= 2 && T >= 4096 && T % 4 == 0 && pmin >= 512) lvl = 2;
+        else if (have && T >= 2048 && T % 2 == 0 && pmin >= 256) lvl = 1;
+    }
+    if (lvl) {
+        const int S = 1 << lvl, ncomp = lvl == 1 ? 3 : 9;
+        const int nh = T / S, ph = e->Pstride >> lvl;
+        const int tiles = (nh + 255) / 256;
         const int tcap = tiles * 256;
         const size_t plane = (size_t)MC_NB * tcap;
         int launched = 0;
         for (int a = 0; a < nact; a++) {
             const ActiveVoice& av = act[a];
-            const int q_end = round_up((av.p_end + 1) / 2, 16);
+            const int q_end = round_up((av.p_end + S - 1) / S, 16);
             const float4* sg = e->d_slotgain + (size_t)av.v * e->ring;
-            for (int c = 0; c < 3; c++) {  // A: even, B: odd (from output -1), C: sum
-                const int nout = c == 1 ? nh + 1 : nh;
-                const dim3 grid(MC_NB * ((nout + 255) / 256));
-                const float4* h0 = av.ir0->d_Hp + (size_t)c * MC_NB * ph;
-                const float4* h1 = av.ir1->d_Hp + (size_t)c * MC_NB * ph;
-                float4* y = e->d_Y + (size_t)c * plane;
-                const int xphase = c == 1 ? 1 : 0, xsum = c == 2 ? 1 : 0, n_first = c == 1 ? -1 : 0;
-                if (av.uniform && !per_slot_gains)
-                    hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, h0, h1, ph, 0, q_end, e->d_fdl, e->ring,
-                                       slot0, nout, av.ugain, sg, y, tcap, launched ? 1 : 0, 1, q_end, 2, xphase, xsum, n_first);
-                else
-                    hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, h0, h1, ph, 0, q_end, e->d_fdl, e->ring,
-                                       slot0, nout, av.ugain, sg, y, tcap, launched ? 1 : 0, 1, q_end, 2, xphase, xsum, n_first);
-            }
+            const dim3 grid(MC_NB * tiles * ncomp);
+            if (av.uniform && !per_slot_gains)
+                hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_Hp[lvl - 1], av.ir1->d_Hp[lvl - 1],
+                                   ph, 0, q_end, e->d_fdl, e->ring, slot0, nh, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0, 1, q_end,
+                                   lvl, tiles, (int64_t)plane);
+            else
+                hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_Hp[lvl - 1], av.ir1->d_Hp[lvl - 1],
+                                   ph, 0, q_end, e->d_fdl, e->ring, slot0, nh, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0, 1, q_end,
+                                   lvl, tiles, (int64_t)plane);
             launched++;
             mo->swept = std::max(mo->swept, av.p_end);
         }
@@ -651,7 +687,20 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         mo->stt = 1;
         mo->nsum = 1;
         mo->sc = 0;
+        mo->lvl = lvl;
         mo->ffa_plane = (int64_t)plane;
+        mo->main_n = T - S;
+        // the last S blocks: streaming kernel, one set of chunk partials per voice
+        mo->tail_n = S;
+        mo->tail_nsum = nact * e->nchunk;
+        for (int a = 0; a < nact; a++) {
+            ActiveVoice av = act[a];
+            if (per_slot_gains) av.uniform = false;
+            launch_mac_stream(e, av, 0, av.p_end, S, (slot0 + T - S) & (e->ring - 1), mo->tail_nsum, a * e->nchunk);
+        }
+        mo->tail_ysrc = e->d_part;
+        mo->tail_sk = mo->tail_nsum;
+        mo->tail_stt = (int64_t)MC_NB * mo->tail_nsum;
         return MC_OK;
     }
     if (mo->resident) {
@@ -671,11 +720,11 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
             if (av.uniform && !per_slot_gains)
                 hipLaunchKernelGGL(k_mac_resident<false>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
                                    p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk, 1, 0, 0, 0);
+                                   psplit, pchunk, 0, tiles, (int64_t)0);
             else
                 hipLaunchKernelGGL(k_mac_resident<true>, grid, dim3(256), 0, e->stream, av.ir0->d_H, av.ir1->d_H, e->Pstride,
                                    p_begin, p_end, e->d_fdl, e->ring, slot0, T, av.ugain, sg, e->d_Y, tcap, launched ? 1 : 0,
-                                   psplit, pchunk, 1, 0, 0, 0);
+                                   psplit, pchunk, 0, tiles, (int64_t)0);
             launched++;
             mo->swept = std::max(mo->swept, p_end - p_begin);
         }
@@ -776,8 +825,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_inv, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
-                           mo.sc, Tc, e->d_seg, e->sr, seg0, e->d_tw, mo.ffa_plane);
+        launch_inv(e, mo, tv);
         hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, (int64_t)tv, (int64_t)d_old,
                            e->d_res_mac, e->rr, (int64_t)new_end);
         tv += (uint64_t)Tc;
@@ -892,9 +940,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 e->kev_n++;
                 e->ks.resident = mo.resident ? 1 : 0;
                 e->ks.partitions = (uint32_t)mo.swept;
+                e->ks.fast_levels = (uint32_t)mo.lvl;
             }
-            hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
-                               mo.sc, n, e->d_seg, e->sr, (int)(b & (uint64_t)(e->sr - 1)), e->d_tw, mo.ffa_plane);
+            launch_inv(e, mo, b);
         }
     }
     if (lin)
@@ -1339,6 +1387,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
     // >= 8 planes of 256 blocks; the fast-FIR form writes three half-rate sequences (1.5 x the blocks, + a tile each)
     ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * y_capacity(e)));
+    if (!e->half) ENG_TRY(hipMalloc(&e->d_Yc, sizeof(float4) * (size_t)MC_NB * e->Tcap));
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
@@ -1369,7 +1418,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
-    if (std::getenv("MCCONV_NO_FFA")) e->ffa = false;
+    if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(2, std::atoi(fl)));
     {
         std::vector<float2> tw;
         host_twiddles(tw);
@@ -1394,7 +1443,8 @@ void mc_destroy(mc_engine* e) {
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
-        if (e->irs[i].d_Hp) (void)hipFree(e->irs[i].d_Hp);
+        for (int l = 0; l < 2; l++)
+            if (e->irs[i].d_Hp[l]) (void)hipFree(e->irs[i].d_Hp[l]);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
@@ -1403,6 +1453,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_slotgain);
     (void)hipFree(e->d_fdl16);
     (void)hipFree(e->d_Y);
+    (void)hipFree(e->d_Yc);
     (void)hipFree(e->d_part);
     (void)hipFree(e->d_sums);
     (void)hipFree(e->d_seg);
@@ -1675,10 +1726,11 @@ int mc_get_kernel_stats(mc_engine* e, mc_kernel_stats* out, int reset) {
     if (rc) return rc;
     *out = e->ks;
     if (reset) {
-        uint32_t res = e->ks.resident, parts = e->ks.partitions;
+        uint32_t res = e->ks.resident, parts = e->ks.partitions, lv = e->ks.fast_levels;
         std::memset(&e->ks, 0, sizeof(e->ks));
         e->ks.resident = res;
         e->ks.partitions = parts;
+        e->ks.fast_levels = lv;
     }
     return MC_OK;
 }

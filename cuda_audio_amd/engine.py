@@ -212,7 +212,7 @@ class Convolution:
         ks = McKernelStats()
         check(self._L.mc_get_kernel_stats(self._h, C.byref(ks), 1 if reset else 0))
         return dict(launches=ks.launches, blocks=ks.blocks, total_ms=ks.total_ms, last_ms=ks.last_ms,
-                    resident=bool(ks.resident), partitions=ks.partitions)
+                    resident=bool(ks.resident), partitions=ks.partitions, fast_levels=ks.fast_levels)
 
     def algorithmic_bytes_per_block(self):
         return self._L.mc_algorithmic_bytes_per_block(self._h)

@@ -1217,26 +1217,28 @@ def test_fp16_storage_with_predelay_changes_and_voice_merges(oracle_mod, gpu_lib
     assert err > 1e-7
 
 
-def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch):
-    """Batches of >= 4096 blocks run the resident MAC in 2-parallel fast-FIR form (three half-rate convolutions over
-    the polyphase components of the block sequence, 3/4 of the multiply-adds).  Same output as the direct form and
-    as the oracle: through the cold-start ramp (per-slot gains), for a batch that starts at an odd block, for a
-    batch length that is not a multiple of the tile, and with two voices (IR switch)."""
+@pytest.mark.parametrize("n_ref,taps,sizes", [(131072, (88200, 80000, 70000), [3, 4098, 4096]),
+                                               (262144, (140000, 150000, 135000), [3, 4100, 4096])],
+                         ids=["one_level_P345", "two_levels_P586"])
+def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, sizes):
+    """Long batches run the resident MAC in fast-FIR form: the convolution along the block axis is split into the
+    polyphase components of the block sequence - three half-rate convolutions (3/4 of the multiply-adds), or nine
+    at a quarter of the rate for long IRs (9/16).  Same output as the direct form and as the oracle: through the
+    cold-start ramp (per-slot gains), for a batch that starts at an odd block, for a batch length that is not a
+    multiple of the tile, and with two voices (IR switch)."""
     from cuda_audio_amd.synth import make_input, make_ir
 
-    n_ref = 131072
-    sizes = [3, 4098, 4096]
     nb = sum(sizes)
     x = make_input(nb * 256)
-    irs = [make_ir(88200, seed=5678, norm=0.02), make_ir(80000, seed=5680, norm=0.02), make_ir(70000, seed=5682, norm=0.02)]
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
     p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
 
     def run(no_ffa):
         if no_ffa:
-            monkeypatch.setenv("MCCONV_NO_FFA", "1")
+            monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
         else:
-            monkeypatch.delenv("MCCONV_NO_FFA", raising=False)
-        c = _conv(fftSize=n_ref, max_batch=4098)
+            monkeypatch.delenv("MCCONV_FFA_LEVELS", raising=False)
+        c = _conv(fftSize=n_ref, max_batch=max(sizes))
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
         apply_params(c, p0, p1, False)
