@@ -166,20 +166,25 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
 //   ffa_mask(c, L) bit j set  <=>  x_c[m] includes X[2^L m + j].
 __host__ __device__ __forceinline__ int ffa_digit_mask(int d) { return d == 0 ? 1 : (d == 1 ? 2 : 3); }
 __host__ __device__ __forceinline__ int ffa_mask(int c, int lvl) {
-    if (lvl == 1) return ffa_digit_mask(c);
-    // level 2: first digit selects residues j1 in {0,1} at stride 2, second digit j2 in {0,1} at stride 4: j = 2 j2 + j1
-    const int m1 = ffa_digit_mask(c / 3), m2 = ffa_digit_mask(c % 3);
-    int m = 0;
-    for (int j2 = 0; j2 < 2; j2++)
-        for (int j1 = 0; j1 < 2; j1++)
-            if (((m2 >> j2) & 1) && ((m1 >> j1) & 1)) m |= 1 << (2 * j2 + j1);
-    return m;
+    // digit l (l = 1 most significant) selects residues j_l in {0,1} at stride 2^l: j = sum_l 2^(l-1) j_l
+    int mask = 1, span = 1;  // residues selected so far, modulo `span`
+    int div = lvl == 1 ? 1 : (lvl == 2 ? 3 : 9);
+    for (int l = 0; l < lvl; l++) {
+        const int dm = ffa_digit_mask((c / div) % 3);
+        int m = 0;
+        if (dm & 1) m |= mask;
+        if (dm & 2) m |= mask << span;
+        mask = m;
+        span *= 2;
+        div /= 3;
+    }
+    return mask;
 }
 
 // Components of an IR's partition sequence (load time): Hp[c][bin][q] = sum_{j in mask(c)} H[bin][2^L q + j],
 // 3^L arrays of pstride / 2^L partitions each.
 __global__ __launch_bounds__(256) void k_polyphase(const float4* __restrict__ H, float4* __restrict__ Hp, int pstride, int lvl) {
-    const int ph = pstride >> lvl, nc = lvl == 1 ? 3 : 9;
+    const int ph = pstride >> lvl, nc = lvl == 1 ? 3 : (lvl == 2 ? 9 : 27);
     const size_t n = (size_t)MC_NB * ph;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n * nc; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i / n);
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
             const int pos = (e & 3) * MAC_WQ + (e >> 2);
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 8; j++) {
                 if (j < xstride && ((xmask >> j) & 1) && e < nwin) {
                     const int slot = (sb + j) & (ring - 1);
                     const float4 x = fk[slot];
@@ -582,34 +587,52 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
 // [bin][tcap], stored from sequence index -1: Z[n] sits at n + 1) into the partition sums of blocks 0 .. T-1,
 // Yc[bin][t].  One level, with A = even, B = odd, C = sum component:
 //   Y[2n] = A[n] + B[n-1],   Y[2n+1] = C[n] - A[n] - B[n];
-// with two levels A, B, C are themselves combined the same way from their own three components.
-// grid = (ceil(T / 256), 256 bins): consecutive threads = consecutive blocks of one bin.
+// with more levels A, B, C are themselves combined the same way from their own three components (component index
+// = base-3 digits, most significant = outermost split).
+// One thread produces the 2^lvl blocks of one group g from the 3^lvl components at indices g - 1 and g.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ffa_combine(const float4* __restrict__ Yp, int64_t plane, int tcap, int lvl, int T,
-                                                     float4* __restrict__ Yc, int ycap) {
-    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
-    if (t >= T) return;
-    const float4* base = Yp + (int64_t)k * tcap + 1;  // + 1: sequences start at index -1
-    auto half_rate = [&](int d1, int n) -> float4 {    // half-rate sequence d1 (0 even, 1 odd, 2 sum) at index n
-        if (lvl == 1) return base[(int64_t)d1 * plane + n];
-        const int kq = n >> 1;  // arithmetic shift: n = -1 -> kq = -1
-        const float4* p = base + (int64_t)(3 * d1) * plane;
-        const float4 za = p[kq], zb = p[plane + kq - ((n & 1) ? 0 : 1)];
-        if ((n & 1) == 0) return make_float4(za.x + zb.x, za.y + zb.y, za.z + zb.z, za.w + zb.w);
-        const float4 zc = p[2 * plane + kq];
-        return make_float4(zc.x - za.x - zb.x, zc.y - za.y - zb.y, zc.z - za.z - zb.z, zc.w - za.w - zb.w);
-    };
-    const int n = t >> 1;
-    const float4 A = half_rate(0, n);
-    float4 y;
-    if ((t & 1) == 0) {
-        const float4 B = half_rate(1, n - 1);
-        y = make_float4(A.x + B.x, A.y + B.y, A.z + B.z, A.w + B.w);
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_cab(float4 c, float4 a, float4 b) {
+    return make_float4(c.x - a.x - b.x, c.y - a.y - b.y, c.z - a.z - b.z, c.w - a.w - b.w);
+}
+
+// out[i] = value at index 2^LVL g - 1 + i (i = 0 .. 2^LVL) of the sequence whose 3^LVL stored components start at
+// plane c0
+template <int LVL>
+__device__ __forceinline__ void ffa_expand(const float4* __restrict__ base, int64_t plane, int c0, int g, float4* out) {
+    if constexpr (LVL == 0) {
+        out[0] = base[(int64_t)c0 * plane + g - 1];
+        out[1] = base[(int64_t)c0 * plane + g];
     } else {
-        const float4 B = half_rate(1, n), C = half_rate(2, n);
-        y = make_float4(C.x - A.x - B.x, C.y - A.y - B.y, C.z - A.z - B.z, C.w - A.w - B.w);
+        constexpr int M = 1 << (LVL - 1);
+        constexpr int W = LVL == 1 ? 1 : (LVL == 2 ? 3 : 9);  // planes per sub-sequence
+        float4 a[M + 1], b[M + 1], c[M + 1];
+        ffa_expand<LVL - 1>(base, plane, c0, g, a);
+        ffa_expand<LVL - 1>(base, plane, c0 + W, g, b);
+        ffa_expand<LVL - 1>(base, plane, c0 + 2 * W, g, c);
+        out[0] = f4_cab(c[0], a[0], b[0]);
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+            out[1 + 2 * u] = f4_add(a[u + 1], b[u]);
+            out[2 + 2 * u] = f4_cab(c[u + 1], a[u + 1], b[u + 1]);
+        }
     }
-    Yc[(size_t)k * ycap + t] = y;
+}
+
+template <int LVL>
+__global__ __launch_bounds__(256) void k_ffa_combine(const float4* __restrict__ Yp, int64_t plane, int tcap, int T,
+                                                     float4* __restrict__ Yc, int ycap) {
+    // grid = (ceil(T / 2^LVL / 256), 256 bins): consecutive threads = consecutive groups of one bin
+    constexpr int S = 1 << LVL;
+    const int g = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (g * S >= T) return;
+    const float4* base = Yp + (int64_t)k * tcap + 1;  // + 1: sequences start at index -1
+    float4 out[S + 1];
+    ffa_expand<LVL>(base, plane, 0, g, out);
+    float4* dst = Yc + (size_t)k * ycap + (size_t)g * S;
+#pragma unroll
+    for (int r = 0; r < S; r++)
+        if (g * S + r < T) dst[r] = out[1 + r];
 }
 
 // ---------------------------------------------------------------------------

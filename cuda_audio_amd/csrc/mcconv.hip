@@ -58,7 +58,7 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 
 struct IrEntry {
     float4* d_H = nullptr;
-    float4* d_Hp[2] = {nullptr, nullptr};  // fast-FIR components of the partition sequence: level 1 (3 arrays), level 2 (9)
+    float4* d_Hp[3] = {nullptr, nullptr, nullptr};  // fast-FIR components of the partition sequence: 3 / 9 / 27 arrays
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -157,7 +157,7 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
-    int ffa_levels = 2;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
+    int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
     bool uniform_valid[2] = {false, false};
@@ -178,7 +178,7 @@ struct mc_engine {
 
 namespace {
 
-size_t y_capacity(const mc_engine* e) { return std::max<size_t>(9 * ((size_t)e->Tcap / 4 + 256) + 1024, 8192); }  // blocks per bin
+size_t y_capacity(const mc_engine* e) { return std::max<size_t>(27 * ((size_t)e->Tcap / 8 + 256) + 1024, 8192); }  // blocks per bin
 
 void host_twiddles(std::vector<float2>& tw) {
     tw.resize(FFT_N);
@@ -238,8 +238,9 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 // fast-FIR components of an IR's spectra (levels 1 and 2) for the resident MAC
 int build_polyphase(mc_engine* e, IrEntry& ir) {
     if (e->half || e->Pstride < 128) return MC_OK;  // the fp16 MAC streams; small engines never use the fast form
-    for (int lvl = 1; lvl <= 2; lvl++) {
-        const size_t n = (size_t)(lvl == 1 ? 3 : 9) * MC_NB * (e->Pstride >> lvl);
+    for (int lvl = 1; lvl <= 3; lvl++) {
+        if ((e->Pstride >> lvl) < 32) break;
+        const size_t n = (size_t)(lvl == 1 ? 3 : (lvl == 2 ? 9 : 27)) * MC_NB * (e->Pstride >> lvl);
         if (!ir.d_Hp[lvl - 1]) HIP_TRY(hipMalloc(&ir.d_Hp[lvl - 1], sizeof(float4) * n));
         hipLaunchKernelGGL(k_polyphase, dim3(2048), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp[lvl - 1], e->Pstride, lvl);
     }
@@ -616,8 +617,14 @@ struct MacOut {
 // inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0`
 void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0) {
     if (mo.main_n > 0 && mo.lvl) {
-        hipLaunchKernelGGL(k_ffa_combine, dim3((mo.main_n + 255) / 256, MC_NB), dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane,
-                           (int)mo.sk, mo.lvl, mo.main_n, e->d_Yc, e->Tcap);
+        const int S = 1 << mo.lvl;
+        const dim3 cgrid(((mo.main_n + S - 1) / S + 255) / 256, MC_NB);
+        if (mo.lvl == 1)
+            hipLaunchKernelGGL(k_ffa_combine<1>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
+        else if (mo.lvl == 2)
+            hipLaunchKernelGGL(k_ffa_combine<2>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
+        else
+            hipLaunchKernelGGL(k_ffa_combine<3>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
         hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, e->d_Yc, (int64_t)e->Tcap,
                            (int64_t)1, 1, (int64_t)0, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
     } else if (mo.main_n > 0) {
@@ -654,13 +661,19 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         bool have = true;
         for (int a = 0; a < nact; a++) {
             pmin = std::min(pmin, act[a].p_end);
-            have = have && act[a].ir0->d_Hp[0] && act[a].ir1->d_Hp[0] && act[a].ir0->d_Hp[1] && act[a].ir1->d_Hp[1];
+            have = have && act[a].ir0->d_Hp[0] && act[a].ir1->d_Hp[0];
         }
-        if (have && e->ffa_levels >= 2 && T >= 4096 && T % 4 == 0 && pmin >= 512) lvl = 2;
+        auto ready = [&](int l) {
+            for (int a = 0; a < nact; a++)
+                if (!act[a].ir0->d_Hp[l - 1] || !act[a].ir1->d_Hp[l - 1]) return false;
+            return true;
+        };
+        if (have && e->ffa_levels >= 3 && T >= 8192 && T % 8 == 0 && pmin >= 1024 && ready(3)) lvl = 3;
+        else if (have && e->ffa_levels >= 2 && T >= 4096 && T % 4 == 0 && pmin >= 512 && ready(2)) lvl = 2;
         else if (have && T >= 2048 && T % 2 == 0 && pmin >= 256) lvl = 1;
     }
     if (lvl) {
-        const int S = 1 << lvl, ncomp = lvl == 1 ? 3 : 9;
+        const int S = 1 << lvl, ncomp = lvl == 1 ? 3 : (lvl == 2 ? 9 : 27);
         const int nh = T / S, ph = e->Pstride >> lvl;
         const int tiles = (nh + 255) / 256;
         const int tcap = tiles * 256;
@@ -1368,7 +1381,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     e->half = cfg->precision == 1;
     if (e->half) e->stream_threshold = e->Tmax + 1;  // the fp16 MAC is the streaming sweep
-    e->Tstream = std::min(e->half ? e->Tmax : e->Tcap, std::max(1, e->stream_threshold - 1));
+    // (at least 8 blocks: the fast-FIR form sends the last 2^levels blocks of a batch through the streaming kernel)
+    e->Tstream = std::min(e->half ? e->Tmax : e->Tcap, std::max(8, e->stream_threshold - 1));
 
 #define ENG_TRY(expr)                                                                                     \
     do {                                                                                                  \
@@ -1418,7 +1432,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
-    if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(2, std::atoi(fl)));
+    if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
         host_twiddles(tw);
@@ -1443,7 +1457,7 @@ void mc_destroy(mc_engine* e) {
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
-        for (int l = 0; l < 2; l++)
+        for (int l = 0; l < 3; l++)
             if (e->irs[i].d_Hp[l]) (void)hipFree(e->irs[i].d_Hp[l]);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);

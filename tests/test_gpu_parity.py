@@ -1217,10 +1217,11 @@ def test_fp16_storage_with_predelay_changes_and_voice_merges(oracle_mod, gpu_lib
     assert err > 1e-7
 
 
-@pytest.mark.parametrize("n_ref,taps,sizes", [(131072, (88200, 80000, 70000), [3, 4098, 4096]),
-                                               (262144, (140000, 150000, 135000), [3, 4100, 4096])],
-                         ids=["one_level_P345", "two_levels_P586"])
-def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, sizes):
+@pytest.mark.parametrize("levels,n_ref,taps,sizes", [(1, 131072, (88200, 80000, 70000), [3, 4098, 4096]),
+                                                      (2, 262144, (140000, 150000, 135000), [3, 4100, 4096]),
+                                                      (3, 524288, (280000, 300000, 270000), [5, 8200, 8192])],
+                         ids=["one_level_P345", "two_levels_P586", "three_levels_P1172"])
+def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, levels, n_ref, taps, sizes):
     """Long batches run the resident MAC in fast-FIR form: the convolution along the block axis is split into the
     polyphase components of the block sequence - three half-rate convolutions (3/4 of the multiply-adds), or nine
     at a quarter of the rate for long IRs (9/16).  Same output as the direct form and as the oracle: through the
@@ -1234,10 +1235,7 @@ def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, n_r
     p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
 
     def run(no_ffa):
-        if no_ffa:
-            monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
-        else:
-            monkeypatch.delenv("MCCONV_FFA_LEVELS", raising=False)
+        monkeypatch.setenv("MCCONV_FFA_LEVELS", "0" if no_ffa else str(levels))
         c = _conv(fftSize=n_ref, max_batch=max(sizes))
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
@@ -1250,17 +1248,21 @@ def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, n_r
             s = slice(o * 256, (o + n) * 256)
             out[:, s] = c.process(x[0, s], x[1, s])
             o += n
+        c.enable_kernel_timing(True)
+        s = slice(0, sizes[-1] * 256)
+        c.process(x[0, s], x[1, s])
         ks = c.kernel_stats()
         c.close()
         return out, ks
 
-    fast, _ = run(False)
-    direct, _ = run(True)
+    fast, ks_fast = run(False)
+    direct, ks_direct = run(True)
+    assert ks_fast["fast_levels"] == levels and ks_direct["fast_levels"] == 0
     assert rms(fast - direct) <= 2e-6, f"fast-FIR vs direct: {rms(fast - direct):.3e}"
     assert rms(fast - direct) > 0  # they really are different computations
     # oracle on the first two batches (float64 partitioned form, which models a constant select; the third batch,
-    # with the IR switch, is covered by the comparison with the direct form above)
-    nchk = sizes[0] + sizes[1]
+    # with the IR switch, is covered by the comparison with the direct form above); the largest case: their start
+    nchk = min(sizes[0] + sizes[1], 1000 if n_ref > 262144 else 1 << 30)
     o = oracle_mod.Upols(n_ref, True)
     for i, ir in enumerate(irs):
         o.prepare(i, ir)
