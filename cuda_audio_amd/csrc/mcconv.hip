@@ -85,6 +85,14 @@ struct mc_engine {
     uint2* d_fdl16 = nullptr;  // fp16 mirror of the delay line (precision = fp16)
     bool half = false;
     float4* d_Yc = nullptr;  // [256][Tcap] partition sums combined from the fast-FIR components
+    // Pipelined batches (mc_config.pipeline): the inverse transforms and the post stage of batch k run on a second
+    // stream under the MAC of batch k + 1.  Scratch that both touch is double-buffered by batch parity.
+    bool pipelined = false;
+    hipStream_t post_stream = nullptr;
+    hipEvent_t ev_mac[2][2], ev_corr[2], ev_post[2];
+    bool post_pending[2] = {false, false};
+    float4 *d_Ybuf[2] = {nullptr, nullptr}, *d_Ycbuf[2] = {nullptr, nullptr}, *d_partbuf[2] = {nullptr, nullptr};
+    float4 *d_tail = nullptr, *d_tailbuf[2] = {nullptr, nullptr};  // chunk partials of the last 2^levels blocks (fast-FIR form)
     float4 *d_fdl = nullptr, *d_slotgain = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sums = nullptr;
     float *d_seg = nullptr, *d_wet = nullptr;
     double* d_cring = nullptr;
@@ -203,7 +211,27 @@ int drain_kernel_events(mc_engine* e) {
     return MC_OK;
 }
 
+// Pipelined mode: nothing of an earlier batch is still running on the post stream
+int drain_post(mc_engine* e) {
+    if (!e->pipelined) return MC_OK;
+    if (e->post_pending[0] || e->post_pending[1]) HIP_TRY(hipStreamSynchronize(e->post_stream));
+    e->post_pending[0] = e->post_pending[1] = false;
+    return MC_OK;
+}
+
+// Pipelined mode: the engine's stream waits for everything issued on the post stream so far
+int fence_post(mc_engine* e) {
+    if (!e->pipelined) return MC_OK;
+    for (int par = 0; par < 2; par++)
+        if (e->post_pending[par]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_post[par], 0));
+    return MC_OK;
+}
+
 int zero_state(mc_engine* e) {
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemsetAsync(e->d_fdl, 0, sizeof(float4) * (size_t)MC_NB * e->ring, e->stream));
     if (e->d_fdl16) HIP_TRY(hipMemsetAsync(e->d_fdl16, 0, sizeof(uint2) * (size_t)MC_NB * e->ring, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_slotgain, 0, sizeof(float4) * (size_t)MC_MAXV * e->ring, e->stream));
@@ -568,7 +596,9 @@ void partition_range(const mc_engine* e, int p_hi, int* p_begin, int* p_end) {
     *p_end = pe;
 }
 
-void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, int T, int slot0, int nsum, int ch_off) {
+void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, int T, int slot0, int nsum, int ch_off,
+                       float4* dst = nullptr) {
+    if (!dst) dst = e->d_part;
     const int nt = e->stream_nt;
     const int span = p_hi - p_lo;
     const int chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
@@ -581,7 +611,7 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
     const float2 inv = make_float2(1.0f / (a.ir0->scale16 * FDL16_SCALE), 1.0f / (a.ir1->scale16 * FDL16_SCALE));
 #define MC_LAUNCH_STREAM(U, NT, H)                                                                                        \
     hipLaunchKernelGGL((k_mac_stream<U, NT, H>), grid, dim3(NT), 0, e->stream, h0, h1, e->Pstride, p_lo, p_hi, chunk, fd, sg, \
-                       e->ring, slot0, e->d_part, nsum, ch_off, a.ugain, inv)
+                       e->ring, slot0, dst, nsum, ch_off, a.ugain, inv)
 #define MC_LAUNCH_STREAM_H(U, NT) \
     do {                          \
         if (half)                 \
@@ -615,24 +645,24 @@ struct MacOut {
 };
 
 // inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0`
-void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0) {
+void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
     if (mo.main_n > 0 && mo.lvl) {
         const int S = 1 << mo.lvl;
         const dim3 cgrid(((mo.main_n + S - 1) / S + 255) / 256, MC_NB);
         if (mo.lvl == 1)
-            hipLaunchKernelGGL(k_ffa_combine<1>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
+            hipLaunchKernelGGL(k_ffa_combine<1>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
         else if (mo.lvl == 2)
-            hipLaunchKernelGGL(k_ffa_combine<2>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
+            hipLaunchKernelGGL(k_ffa_combine<2>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
         else
-            hipLaunchKernelGGL(k_ffa_combine<3>, cgrid, dim3(256), 0, e->stream, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, e->d_Yc, (int64_t)e->Tcap,
+            hipLaunchKernelGGL(k_ffa_combine<3>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, e->d_Yc, (int64_t)e->Tcap,
                            (int64_t)1, 1, (int64_t)0, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
     } else if (mo.main_n > 0) {
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.ysrc, mo.sk, mo.stt, mo.nsum,
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, mo.ysrc, mo.sk, mo.stt, mo.nsum,
                            mo.sc, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
     }
     if (mo.tail_n > 0)
-        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, mo.tail_ysrc, mo.tail_sk,
+        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, mo.tail_ysrc, mo.tail_sk,
                            mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, e->d_seg, e->sr,
                            (int)((b0 + (uint64_t)mo.main_n) & (uint64_t)(e->sr - 1)), e->d_tw);
 }
@@ -709,9 +739,9 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         for (int a = 0; a < nact; a++) {
             ActiveVoice av = act[a];
             if (per_slot_gains) av.uniform = false;
-            launch_mac_stream(e, av, 0, av.p_end, S, (slot0 + T - S) & (e->ring - 1), mo->tail_nsum, a * e->nchunk);
+            launch_mac_stream(e, av, 0, av.p_end, S, (slot0 + T - S) & (e->ring - 1), mo->tail_nsum, a * e->nchunk, e->d_tail);
         }
-        mo->tail_ysrc = e->d_part;
+        mo->tail_ysrc = e->d_tail;
         mo->tail_sk = mo->tail_nsum;
         mo->tail_stt = (int64_t)MC_NB * mo->tail_nsum;
         return MC_OK;
@@ -807,6 +837,10 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
     }
     if (e->pipe_count) return fail(MC_ERR_STATE, "predelay change / voice merge while a batch awaits mc_finish_batch_device");
     if (e->sliced) return fail(MC_ERR_STATE, "predelay change / voice merge on a block-sliced engine (mc_reset first)");
+    {
+        int rc = drain_post(e);  // the rings below are rewritten
+        if (rc) return rc;
+    }
     const uint64_t b0 = e->t_front, bs = e->epoch_b0, d_old = e->cur_delay;
     // the latest old call started at block b0 - pm; the reference cuts its contribution n_ref samples later
     const uint64_t new_end = (b0 - (uint64_t)e->pm) * MC_B + e->cfg.n_ref;
@@ -838,7 +872,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
-        launch_inv(e, mo, tv);
+        launch_inv(e, mo, tv, e->stream);
         hipLaunchKernelGGL(k_flush_ola, dim3(Tc), dim3(256), 0, e->stream, e->d_seg, e->sr, (int64_t)tv, (int64_t)d_old,
                            e->d_res_mac, e->rr, (int64_t)new_end);
         tv += (uint64_t)Tc;
@@ -877,6 +911,22 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     if (slice && lin) return fail(MC_ERR_ARG, "a partition shard cannot be block-sliced");
     if (slice && e->res_end > e->t_front * MC_B) return fail(MC_ERR_STATE, "block-sliced call while a retired predelay epoch is ringing out");
     if (!slice && e->sliced) return fail(MC_ERR_STATE, "whole-batch call on a block-sliced engine (mc_reset first)");
+    // pipelined: this batch's parity owns one set of scratch buffers and one slot of the parameter tables; the
+    // post stage of the batch two calls ago must be done with them
+    const bool piped = e->pipelined && !lin;
+    const int par = (int)(e->batch_seq & 1);
+    if (e->pipelined && !piped) {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
+    if (piped) {
+        if (e->post_pending[par]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_post[par], 0));
+        e->d_Y = e->d_Ybuf[par];
+        e->d_Yc = e->d_Ycbuf[par];
+        e->d_part = e->d_partbuf[par];
+        e->d_tail = e->d_tailbuf[par];
+    }
+    const hipStream_t inv_stream = piped ? e->post_stream : e->stream;
     Staged st;
     int halo = 0;  // blocks before the slice that the predelay and the overlap-add reach back to
     {
@@ -955,7 +1005,16 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 e->ks.partitions = (uint32_t)mo.swept;
                 e->ks.fast_levels = (uint32_t)mo.lvl;
             }
-            launch_inv(e, mo, b);
+            if (piped) {  // the inverse transforms wait for this MAC on the post stream; the engine's stream moves on
+                HIP_TRY(hipEventRecord(e->ev_mac[par][h], e->stream));
+                HIP_TRY(hipStreamWaitEvent(inv_stream, e->ev_mac[par][h], 0));
+            }
+            launch_inv(e, mo, b, inv_stream);
+            if (piped && h == 0 && count < e->stream_threshold) {
+                // both parts would use the streaming kernel's partial buffer: the second waits for the first's reader
+                HIP_TRY(hipEventRecord(e->ev_mac[par][0], inv_stream));
+                HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_mac[par][0], 0));
+            }
         }
     }
     if (lin)
@@ -988,12 +1047,23 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         if (nchunks > 1)  // a single chunk adds its base itself
             hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
                                e->d_ctot);
-        hipLaunchKernelGGL(k_post, dim3(ctx.count), dim3(256), 0, e->stream, e->d_seg, e->sr, lin_sum, e->d_wet, e->wr, e->d_cring,
+        const bool piped = e->pipelined && !lin_sum && !publish;
+        hipStream_t ps = e->stream;
+        if (piped) {  // k_post follows this batch's inverse transforms on the post stream, after the prefix sums
+            HIP_TRY(hipEventRecord(e->ev_corr[ctx.slot], e->stream));
+            HIP_TRY(hipStreamWaitEvent(e->post_stream, e->ev_corr[ctx.slot], 0));
+            ps = e->post_stream;
+        }
+        hipLaunchKernelGGL(k_post, dim3(ctx.count), dim3(256), 0, ps, e->d_seg, e->sr, lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first,
                            (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
                            make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
                            publish ? ++e->flag_seq : 0u, e->d_done_ctr);
         HIP_TRY(hipGetLastError());
+        if (piped) {
+            HIP_TRY(hipEventRecord(e->ev_post[ctx.slot], e->post_stream));
+            e->post_pending[ctx.slot] = true;
+        }
     }
     e->t_abs = ctx.t0 + (uint64_t)T;
     return MC_OK;
@@ -1027,6 +1097,10 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     const size_t cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
@@ -1158,6 +1232,7 @@ int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, 
     int rc = run_front(e, e->d_io[0], e->d_io[1], T, nullptr, 0, T);
     if (rc) return rc;
     rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], T);
+    if (!rc) rc = fence_post(e);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(e->h_io + 2 * cap, e->d_io[2], bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_io + 3 * cap, e->d_io[3], bytes, hipMemcpyDeviceToHost, e->stream));
@@ -1172,13 +1247,19 @@ int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, 
 int process_period(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     const int T = e->pm;
     const size_t bytes = (size_t)T * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, bytes);
     std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    const bool was_piped = e->pipelined;
+    e->pipelined = false;  // a period is finished inside this call
     int rc = run_front(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, T, nullptr, 0, T);
-    if (rc) return rc;
-    rc = run_back(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, nullptr, e->hd_io + 2 * cap, e->hd_io + 3 * cap, T, true);
+    if (!rc) rc = run_back(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, nullptr, e->hd_io + 2 * cap, e->hd_io + 3 * cap, T, true);
+    e->pipelined = was_piped;
     if (rc) return rc;
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     rc = wait_period(e);
@@ -1194,6 +1275,10 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     const int pm = e->pm;
     const size_t bytes = (size_t)pm * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, bytes);
@@ -1363,7 +1448,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->ring = (int)next_pow2((uint64_t)e->Pstride + (uint64_t)e->Tcap + 64);  // + reach-back of a block slice (<= 33)
     e->sr = (int)next_pow2((uint64_t)e->Tcap + 4);  // power of two: ring indices are masks in the kernels; a slice + reach-back <= Tmax
     e->wr = (int)next_pow2((uint64_t)MC_MAX_PREDELAY + (uint64_t)e->Tmax * MC_B + 2 * MC_B);
-    e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax + 64);
+    e->pipelined = cfg->pipeline != 0 && cfg->precision == 0;
+    // (pipelined: the forward stage of batch k + 1 writes histories while the post stage of batch k still reads them)
+    e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax * (e->pipelined ? 2 : 1) + 64);
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
     if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
     if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
@@ -1402,7 +1489,26 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     // >= 8 planes of 256 blocks; the fast-FIR form writes three half-rate sequences (1.5 x the blocks, + a tile each)
     ENG_TRY(hipMalloc(&e->d_Y, sizeof(float4) * (size_t)MC_NB * y_capacity(e)));
     if (!e->half) ENG_TRY(hipMalloc(&e->d_Yc, sizeof(float4) * (size_t)MC_NB * e->Tcap));
+    ENG_TRY(hipMalloc(&e->d_tail, sizeof(float4) * (size_t)8 * MC_NB * e->nchunk * MC_MAXV));
+    e->d_Ybuf[0] = e->d_Y;
+    e->d_Ycbuf[0] = e->d_Yc;
+    e->d_tailbuf[0] = e->d_tail;
+    if (e->pipelined) {
+        ENG_TRY(hipStreamCreateWithFlags(&e->post_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            ENG_TRY(hipEventCreateWithFlags(&e->ev_mac[i][0], hipEventDisableTiming));
+            ENG_TRY(hipEventCreateWithFlags(&e->ev_mac[i][1], hipEventDisableTiming));
+            ENG_TRY(hipEventCreateWithFlags(&e->ev_corr[i], hipEventDisableTiming));
+            ENG_TRY(hipEventCreateWithFlags(&e->ev_post[i], hipEventDisableTiming));
+        }
+        ENG_TRY(hipMalloc(&e->d_Ybuf[1], sizeof(float4) * (size_t)MC_NB * y_capacity(e)));
+        ENG_TRY(hipMalloc(&e->d_Ycbuf[1], sizeof(float4) * (size_t)MC_NB * e->Tcap));
+        ENG_TRY(hipMalloc(&e->d_tailbuf[1], sizeof(float4) * (size_t)8 * MC_NB * e->nchunk * MC_MAXV));
+    }
     ENG_TRY(hipMalloc(&e->d_part, sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
+    e->d_partbuf[0] = e->d_part;
+    if (cfg->pipeline != 0 && cfg->precision == 0)
+        ENG_TRY(hipMalloc(&e->d_partbuf[1], sizeof(float4) * (size_t)e->Tstream * MC_NB * e->nchunk * MC_MAXV));
     ENG_TRY(hipMalloc(&e->d_sums, sizeof(float4) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_seg, sizeof(float) * (size_t)e->sr * 2 * FFT_N));
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
@@ -1411,7 +1517,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->rr = (int)next_pow2(cfg->n_ref);
     ENG_TRY(hipMalloc(&e->d_res_mac, sizeof(float) * 2 * (size_t)e->rr));
     ENG_TRY(hipMalloc(&e->d_res_fix, sizeof(float) * 2 * (size_t)e->rr));
-    e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B + MC_MAX_PREDELAY + 1024);
+    e->xr = (int)next_pow2(cfg->n_ref + (uint64_t)e->Tmax * MC_B * (e->pipelined ? 2 : 1) + MC_MAX_PREDELAY + 1024);
     ENG_TRY(hipMalloc(&e->d_xhist, sizeof(float) * 2 * (size_t)e->xr));
     ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
     ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
@@ -1466,9 +1572,21 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_fdl);
     (void)hipFree(e->d_slotgain);
     (void)hipFree(e->d_fdl16);
-    (void)hipFree(e->d_Y);
-    (void)hipFree(e->d_Yc);
-    (void)hipFree(e->d_part);
+    if (e->post_stream) (void)hipStreamSynchronize(e->post_stream);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(e->d_Ybuf[i]);
+        (void)hipFree(e->d_Ycbuf[i]);
+        (void)hipFree(e->d_tailbuf[i]);
+        if (e->post_stream) {
+            (void)hipEventDestroy(e->ev_mac[i][0]);
+            (void)hipEventDestroy(e->ev_mac[i][1]);
+            (void)hipEventDestroy(e->ev_corr[i]);
+            (void)hipEventDestroy(e->ev_post[i]);
+        }
+    }
+    if (e->post_stream) (void)hipStreamDestroy(e->post_stream);
+    (void)hipFree(e->d_partbuf[0]);
+    (void)hipFree(e->d_partbuf[1]);
     (void)hipFree(e->d_sums);
     (void)hipFree(e->d_seg);
     (void)hipFree(e->d_wet);
@@ -1528,6 +1646,10 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     const int P = (int)((n + MC_B - 1) / MC_B);
     if (P > e->Pcap) return fail(MC_ERR_ARG, "IR needs %d partitions, engine capacity is %d", P, e->Pcap);
     IrEntry& ir = e->irs[idx];
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!ir.d_H) HIP_TRY(hipMalloc(&ir.d_H, sizeof(float4) * (size_t)MC_NB * e->Pstride));
     float* d_lr = nullptr;
@@ -1699,13 +1821,34 @@ int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2,
 int mc_sync(mc_engine* e) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    int rc = drain_post(e);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return MC_OK;
+}
+
+int mc_fence(mc_engine* e) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    return fence_post(e);
+}
+
+int mc_fence_older(mc_engine* e) {
+    if (!e) return fail(MC_ERR_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->pipelined || e->batch_seq == 0) return MC_OK;
+    const int older = (int)(e->batch_seq & 1);  // the most recent batch had parity (batch_seq - 1) & 1
+    if (e->post_pending[older]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_post[older], 0));
     return MC_OK;
 }
 
 int mc_set_stream(mc_engine* e, void* s) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    {
+        int rc = drain_post(e);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = s ? (hipStream_t)s : e->own_stream;
     return MC_OK;

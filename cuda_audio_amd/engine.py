@@ -80,7 +80,7 @@ class CC:
 
 class Convolution:
     def __init__(self, name="Conv", fftSize=CONV_DEFAULT_FFTSIZE, *, max_batch=256, device=-1, compat=True,
-                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32", period=256):
+                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32", period=256, pipeline=False):
         self.name = name
         self._L = _lib.load()
         cfg = McConfig()
@@ -94,6 +94,7 @@ class Convolution:
         cfg.stream_threshold = stream_threshold
         cfg.precision = {"fp32": 0, "fp16": 1}[precision]
         cfg.period = period
+        cfg.pipeline = 1 if pipeline else 0
         h = C.c_void_p()
         check(self._L.mc_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -181,6 +182,15 @@ class Convolution:
 
     def sync(self):
         check(self._L.mc_sync(self._h))
+
+    def fence(self):
+        """Pipelined engines: the engine's stream waits for every batch issued so far (outputs complete in stream
+        order after this)."""
+        check(self._L.mc_fence(self._h))
+
+    def fence_older(self):
+        """... every batch except the most recently issued one."""
+        check(self._L.mc_fence_older(self._h))
 
     def set_stream(self, stream_ptr):
         """hipStream_t as an int; None / 0 = the engine's own non-blocking stream (NOT ordered with the default

@@ -72,7 +72,13 @@ typedef struct {
                                reference's per-call semantics (cross-fade step, DC/Nyquist and tail-drop windows)
                                follow this size; internally a period is 1, 2 or 4 blocks of 256.  Batch calls
                                take multiples of period/256 blocks. */
-    uint32_t reserved[3];
+    uint32_t pipeline;      /* 1 = pipelined batches: mc_process_batch_device / _slice_device return once the MAC of
+                               the batch is queued; its inverse transforms and post stage run on a second stream
+                               under the MAC of the next batch.  The outputs of a call are complete, in the order of
+                               the engine's stream, only after mc_fence (or mc_sync); its inputs must stay valid
+                               until then.  Other calls drain the pipeline first.  0 = every call is complete in
+                               stream order (default). */
+    uint32_t reserved[2];
 } mc_config;
 
 /* mirrors Convolution::CC::value (conv.h:38-49); same defaults via mc_default_params */
@@ -156,6 +162,11 @@ int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2,
                            float *d_outL, float *d_outR, uint64_t nblocks);
 
 int mc_sync(mc_engine *e);
+/* pipelined engines: the engine's stream waits for everything issued so far (no host synchronisation) */
+int mc_fence(mc_engine *e);
+/* ... for everything except the most recently issued batch (so that the consumer of batch k - 1 can be queued
+ * behind batch k without stalling batch k + 1 on the post stage of k) */
+int mc_fence_older(mc_engine *e);
 /* hip_stream is a hipStream_t.  NULL selects the engine's own stream, which is NON-BLOCKING: it is not ordered
  * with HIP's default stream.  A caller whose buffers are produced or consumed on the default stream (PyTorch's
  * current stream unless one is set) must pass that stream explicitly - MC_STREAM_DEFAULT, HIP's hipStreamLegacy

@@ -1270,3 +1270,47 @@ def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, lev
     want = o.process(x[0, : nchk * 256], x[1, : nchk * 256])
     err = rms(fast[:, : nchk * 256] - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+@pytest.mark.parametrize("n_ref,taps,T,pd,sliced", [(8192, (5000, 4000), 40, 700, False), (4096, (3072, 3072), 24, 1024, False),
+                                                     (131072, (88200, 80000), 4096, 0, False), (8192, (5000, 4000), 48, 300, True)],
+                         ids=["small_batches", "taildrop", "fast_fir_batches", "block_slices"])
+def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced):
+    """mc_config.pipeline: the inverse transforms and the post stage of batch k run on a second stream under the MAC
+    of batch k + 1; nothing is synchronised between the calls, one fence at the end.  Bit-for-bit the output of the
+    unpipelined engine (same kernels, same order of arithmetic)."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nbat = 7
+    x = make_input(nbat * T * 256)
+    irs = [make_ir(taps[0], seed=11, norm=0.05), make_ir(taps[1], seed=22, norm=0.05)]
+    p0, p1 = dict(BASE, predelay=pd, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
+    st = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(st):
+        dx = torch.from_numpy(x).cuda()
+        for piped in (False, True):
+            c = _conv(fftSize=n_ref, max_batch=T + 16, pipeline=piped)
+            for i, ir in enumerate(irs):
+                c.prepare(i, ir)
+            apply_params(c, p0, p1, False)
+            c.use_torch_stream(st)
+            first, count = (T // 3, T // 3) if sliced else (0, T)
+            out = torch.zeros(nbat, 2, count * 256, device="cuda")
+            for k in range(nbat):
+                if k == 4:
+                    c.cc[1].value.wet = 0.3  # a parameter change between two batches in flight
+                sl = slice(k * T * 256, (k + 1) * T * 256)
+                i1, i2 = dx[0, sl], dx[1, sl]
+                if sliced:
+                    c.process_slice_device(i1.data_ptr(), i2.data_ptr(), out[k, 0].data_ptr(), out[k, 1].data_ptr(), T, first, count)
+                else:
+                    c.process_device(i1.data_ptr(), i2.data_ptr(), out[k, 0].data_ptr(), out[k, 1].data_ptr(), T)
+            c.fence()
+            st.synchronize()
+            outs.append(out.cpu().numpy())
+            c.close()
+    assert rms(outs[0]) > 1e-3
+    assert np.array_equal(outs[0], outs[1]), f"rms difference {rms(outs[0] - outs[1]):.3e}"
