@@ -1693,3 +1693,266 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
         __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+// ---------------------------------------------------------------------------
+// Second-level transform along the block axis (long batches, uniform gains).
+// Per bin the partition sum Y[t] = sum_p H[p] X[t - p] is a convolution along
+// the block axis; with thousands of outputs per launch it is done as one
+// circular convolution of length F2_N per (bin, chunk of blocks): forward
+// transforms of the two input sequences, products with the transformed
+// partition sequences of the IRs, inverse transforms (overlap-save: the first
+// P - 1 outputs of the circle are discarded).  One workgroup of 1024 threads
+// holds a whole sequence in LDS (128 KB of gfx950's 160).  The forward
+// transform is a decimation-in-frequency radix-4 (natural in, digit-reversed
+// out), the inverse a decimation-in-time radix-4 (digit-reversed in, natural
+// out) - the exact stage-by-stage inverse - so the spectra never need
+// reordering: the IR's second-level spectra are stored in the same
+// digit-reversed order (k_fft2_ir).
+// Bin 0 packs two real bins {DC, Nyquist} as one complex number z; their two
+// real filters act as  y = h1 * z + h2 * conj(z),  h1 = (h_dc + h_ny)/2,
+// h2 = (h_dc - h_ny)/2, so bin 0 transforms conj(z) as well.
+// ---------------------------------------------------------------------------
+#define F2_N 16384
+#define F2_THREADS 1024
+
+__device__ __forceinline__ float2 f2_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 f2_mulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// w^e, w = exp(-2 pi i / F2_N): t_lo[k] = w^k, t_hi[k] = w^(128 k), k < 128
+__device__ __forceinline__ float2 f2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
+
+__device__ __forceinline__ void f2_tables(float2* t_lo, float2* t_hi) {
+    if (threadIdx.x < 256) {
+        const int k = threadIdx.x & 127;
+        const float frac = (threadIdx.x < 128 ? (float)k : (float)(128 * k)) * (-2.0f / (float)F2_N);
+        float sn, cs;
+        sincospif(frac, &sn, &cs);
+        (threadIdx.x < 128 ? t_lo : t_hi)[k] = make_float2(cs, sn);
+    }
+}
+
+// LDS layout of a sequence: element i lives at F2_P(i) - one pad entry per 64 elements, so that the last three
+// radix-4 stages (which stay inside aligned groups of 64 elements) can put consecutive lanes on consecutive GROUPS
+// without bank conflicts (stride 65 entries), while the first four stages put consecutive lanes on consecutive
+// elements.
+#define F2_P(i) ((i) + ((i) >> 6))
+#define F2_LDS (F2_N + F2_N / 64)
+
+// radix-4 butterfly in place: forward y_m = sum_n a_n (-j)^(mn), inverse with +j
+template <bool INV>
+__device__ __forceinline__ void f2_bfly4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y), t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y), t3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+    a0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+    a2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+    if (INV) {
+        a1 = make_float2(t1.x - t3.y, t1.y + t3.x);
+        a3 = make_float2(t1.x + t3.y, t1.y - t3.x);
+    } else {
+        a1 = make_float2(t1.x + t3.y, t1.y - t3.x);
+        a3 = make_float2(t1.x - t3.y, t1.y + t3.x);
+    }
+}
+// a1, a2, a3 *= w, w^2, w^3 (INV: their conjugates)
+template <bool INV>
+__device__ __forceinline__ void f2_tw3(float2& a1, float2& a2, float2& a3, float2 w) {
+    if (INV) w.y = -w.y;
+    const float2 w2 = f2_mul(w, w), w3 = f2_mul(w2, w);
+    a1 = f2_mul(a1, w);
+    a2 = f2_mul(a2, w2);
+    a3 = f2_mul(a3, w3);
+}
+
+// Two consecutive radix-4 stages on the 16 elements pos0 + Q m (m = 0..15) of a thread, in registers: the stage
+// with quarter length 4 Q (butterflies over m = r, r+4, r+8, r+12) and the stage with quarter length Q (m = 4g .. 4g+3).
+// j0 = pos0 mod Q.  Forward: decimation in frequency (butterfly, then twiddle), first the wide stage; the inverse
+// undoes them in the opposite order (conjugate twiddle, then inverse butterfly).
+template <bool INV>
+__device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
+    const int Q = 1 << lq;
+    const int step1 = F2_N >> (lq + 4), step2 = F2_N >> (lq + 2);
+    float2 a[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) a[m] = s[F2_P(pos0 + Q * m)];
+    if (!INV) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            f2_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            f2_tw3<false>(a[r + 4], a[r + 8], a[r + 12], f2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+        }
+        const float2 w = f2_tw(t_lo, t_hi, j0 * step2);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            f2_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            f2_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+        }
+    } else {
+        const float2 w = f2_tw(t_lo, t_hi, j0 * step2);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            f2_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            f2_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            f2_tw3<true>(a[r + 4], a[r + 8], a[r + 12], f2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            f2_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) s[F2_P(pos0 + Q * m)] = a[m];
+}
+
+// the last forward / first inverse stage (quarter length 1, no twiddles): four butterflies per thread on quads of
+// different 64-element groups (consecutive lanes: consecutive groups)
+template <bool INV>
+__device__ __forceinline__ void f2_quads(float2* s, int t) {
+    const int G = t & 255, u0 = t >> 8;
+    float2 a[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[4 * r + k] = s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)];
+#pragma unroll
+    for (int r = 0; r < 4; r++) f2_bfly4<INV>(a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)] = a[4 * r + k];
+}
+
+// natural order in, digit-reversed order out (unscaled forward transform); every pass moves the sequence through
+// registers in 1024 pieces of 16 elements
+#define F2_PIECES (F2_N / 16)
+__device__ __forceinline__ void f2_forward(float2* s, const float2* t_lo, const float2* t_hi) {
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<false>(s, t_lo, t_hi, t, t, 10);  // quarter lengths 4096, 1024
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
+        f2_pair<false>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63, 6);  // 256, 64
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
+        f2_pair<false>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);  // 16, 4
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<false>(s, t);  // 1
+    __syncthreads();
+}
+
+// digit-reversed order in, natural order out (unscaled inverse: F2_N times the input sequence)
+__device__ __forceinline__ void f2_inverse(float2* s, const float2* t_lo, const float2* t_hi) {
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<true>(s, t);
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
+        f2_pair<true>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
+        f2_pair<true>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63, 6);
+    __syncthreads();
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<true>(s, t_lo, t_hi, t, t, 10);
+    __syncthreads();
+}
+
+// Second-level spectra of an IR: for channel c (0 = L, 1 = R) and row r (bins 0 .. 255, row 256 = bin 0's h2)
+// the forward transform of the zero-padded partition sequence, digit-reversed order:
+// out[(c * 257 + r) * F2_N + i].   grid = (257, 2), block = 1024.
+__global__ __launch_bounds__(F2_THREADS) void k_fft2_ir(const float4* __restrict__ H, int pstride, int P, float2* __restrict__ out) {
+    __shared__ float2 s[F2_LDS];
+    __shared__ float2 t_lo[128], t_hi[128];
+    const int row = blockIdx.x, c = blockIdx.y, bin = row == 256 ? 0 : row;
+    f2_tables(t_lo, t_hi);
+    for (int i = threadIdx.x; i < F2_N; i += F2_THREADS) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < P) {
+            const float4 h = H[(size_t)bin * pstride + i];
+            const float2 hc = c == 0 ? make_float2(h.x, h.y) : make_float2(h.z, h.w);
+            if (bin != 0)
+                v = hc;
+            else  // hc = {h_dc, h_ny}: both real
+                v = make_float2(row == 0 ? 0.5f * (hc.x + hc.y) : 0.5f * (hc.x - hc.y), 0.f);
+        }
+        s[F2_P(i)] = v;
+    }
+    __syncthreads();
+    f2_forward(s, t_lo, t_hi);
+    float2* dst = out + ((size_t)c * 257 + row) * F2_N;
+    for (int i = threadIdx.x; i < F2_N; i += F2_THREADS) dst[i] = s[F2_P(i)];
+}
+
+struct Fft2Voices {
+    int n;
+    const float2* h0[MC_MAXV];  // second-level spectra of the voice's IR for input 1 / input 2
+    const float2* h1[MC_MAXV];
+    float4 g[MC_MAXV];          // {L<-in1, L<-in2, R<-in1, R<-in2}
+};
+
+// grid = (256 bins, chunks), block = 1024.  Chunk c covers output blocks [c * chunk_t, ...) of the batch;
+// taps = partitions swept (>= every voice's), chunk_t + taps - 1 <= F2_N.
+// stash: [(chunk * 256 + bin) * 4 + k][F2_N] scratch: the transformed input sequences, re-read by the two product passes.
+__global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                        int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap,
+                                                        float2* __restrict__ stash) {
+    __shared__ float2 s[F2_LDS];
+    __shared__ float2 t_lo[128], t_hi[128];
+    constexpr int R = F2_N / F2_THREADS;
+    const int bin = blockIdx.x, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+    const float4* fk = fdl + (size_t)bin * ring;
+    const int sb = slot0 + t_c0 - (taps - 1);
+    float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 4 * F2_N;
+    f2_tables(t_lo, t_hi);
+    // transforms, in the order {x1, conj x1 (bin 0), x2, conj x2 (bin 0)}, parked in the stash
+    const int nvar = bin == 0 ? 2 : 1, nseq = 2 * nvar;
+    for (int q = 0; q < nseq; q++) {
+        const int i = q / nvar, var = q - i * nvar;
+        __syncthreads();  // the previous round's readers of s are done (also orders the tables)
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int n = threadIdx.x + F2_THREADS * r;
+            v[r] = make_float2(0.f, 0.f);
+            if (n < L) {
+                const float4 x = fk[(sb + n) & (ring - 1)];
+                v[r] = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
+                if (var) v[r].y = -v[r].y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) s[F2_P(threadIdx.x + F2_THREADS * r)] = v[r];
+        __syncthreads();
+        f2_forward(s, t_lo, t_hi);
+#pragma unroll
+        for (int r = 0; r < R; r++) my[(size_t)q * F2_N + threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
+    }
+    // per output channel: Y_c = sum over sequences and voices of gain * spectrum * IR spectrum, inverse transform,
+    // the valid part of the circle (its first taps - 1 outputs are discarded) to Yc
+    const float sc = 1.0f / (float)F2_N;
+    for (int c = 0; c < 2; c++) {
+        __syncthreads();  // the previous pass's readers of s are done
+#pragma unroll 4
+        for (int r = 0; r < R; r++) {
+            const int idx = threadIdx.x + F2_THREADS * r;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int q = 0; q < nseq; q++) {
+                const int i = q / nvar, var = q - i * nvar;
+                const float2 S = my[(size_t)q * F2_N + idx];
+                const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N + idx;
+#pragma unroll
+                for (int vi = 0; vi < MC_MAXV; vi++) {
+                    if (vi >= vv.n) break;
+                    const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
+                    const float g = c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w);
+                    const float2 p = f2_mul(S, h[row]);
+                    acc.x = fmaf(g, p.x, acc.x);
+                    acc.y = fmaf(g, p.y, acc.y);
+                }
+            }
+            s[F2_P(idx)] = acc;
+        }
+        __syncthreads();
+        f2_inverse(s, t_lo, t_hi);
+        float2* dst = reinterpret_cast<float2*>(Yc + (size_t)bin * ycap + t_c0) + c;  // .xy = Y_L, .zw = Y_R
+        for (int t = threadIdx.x; t < nout; t += F2_THREADS) {
+            const float2 y = s[F2_P(t + taps - 1)];
+            dst[2 * (size_t)t] = make_float2(y.x * sc, y.y * sc);
+        }
+    }
+}

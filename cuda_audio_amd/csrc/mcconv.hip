@@ -59,6 +59,8 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 struct IrEntry {
     float4* d_H = nullptr;
     float4* d_Hp[3] = {nullptr, nullptr, nullptr};  // fast-FIR components of the partition sequence: 3 / 9 / 27 arrays
+    float2* d_H2 = nullptr;  // second-level spectra [2 ch][257 rows][F2_N], built on first use (k_fft2_ir)
+    bool h2_valid = false;
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -85,6 +87,8 @@ struct mc_engine {
     uint2* d_fdl16 = nullptr;  // fp16 mirror of the delay line (precision = fp16)
     bool half = false;
     float4* d_Yc = nullptr;  // [256][Tcap] partition sums combined from the fast-FIR components
+    float2* d_stash = nullptr;  // second-level transform: spectra parked between the transforms and the products
+    size_t stash_chunks = 0;
     // Pipelined batches (mc_config.pipeline): the inverse transforms and the post stage of batch k run on a second
     // stream under the MAC of batch k + 1.  Scratch that both touch is double-buffered by batch parity.
     bool pipelined = false;
@@ -165,6 +169,7 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
+    bool fft2 = true;     // long uniform-gain batches: second-level transform along the block axis instead of the MAC
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
@@ -265,6 +270,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 
 // fast-FIR components of an IR's spectra (levels 1 and 2) for the resident MAC
 int build_polyphase(mc_engine* e, IrEntry& ir) {
+    ir.h2_valid = false;  // the spectra changed: the second-level spectra are rebuilt on next use
     if (e->half || e->Pstride < 128) return MC_OK;  // the fp16 MAC streams; small engines never use the fast form
     for (int lvl = 1; lvl <= 3; lvl++) {
         if ((e->Pstride >> lvl) < 32) break;
@@ -273,6 +279,17 @@ int build_polyphase(mc_engine* e, IrEntry& ir) {
         hipLaunchKernelGGL(k_polyphase, dim3(2048), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp[lvl - 1], e->Pstride, lvl);
     }
     HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// second-level spectra of an IR (transform of its partition sequence along the block axis), built on first use
+int ensure_fft2(mc_engine* e, const IrEntry* irc) {
+    IrEntry& ir = *const_cast<IrEntry*>(irc);
+    if (ir.h2_valid) return MC_OK;
+    if (!ir.d_H2) HIP_TRY(hipMalloc(&ir.d_H2, sizeof(float2) * (size_t)2 * 257 * F2_N));
+    hipLaunchKernelGGL(k_fft2_ir, dim3(257, 2), dim3(F2_THREADS), 0, e->stream, ir.d_H, e->Pstride, std::min(ir.P, F2_N), ir.d_H2);
+    HIP_TRY(hipGetLastError());
+    ir.h2_valid = true;
     return MC_OK;
 }
 
@@ -646,7 +663,7 @@ struct MacOut {
 
 // inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0`
 void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
-    if (mo.main_n > 0 && mo.lvl) {
+    if (mo.main_n > 0 && mo.lvl > 0) {
         const int S = 1 << mo.lvl;
         const dim3 cgrid(((mo.main_n + S - 1) / S + 255) / 256, MC_NB);
         if (mo.lvl == 1)
@@ -685,6 +702,50 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     // kernel covers all components; k_inv combines them.  Every component is computed for sequence indices
     // -1 .. T/2^L - 2, which covers the first T - 2^L blocks of the batch; the last 2^L blocks go through the
     // streaming kernel, so that no tile is spent on one extra output.
+    // Long batches whose window carries one set of gains: the convolution along the block axis as a circular
+    // convolution per (bin, chunk of blocks) with a second-level transform of length F2_N (k_mac_fft); the IRs'
+    // partition sequences are transformed once (k_fft2_ir).  O(log) instead of O(P) work per output block.
+    if (mo->resident && e->fft2 && !per_slot_gains && !e->half && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0 &&
+        T >= 2048) {
+        int pmax = 0;
+        bool ok = true;
+        for (int a = 0; a < nact; a++) {
+            pmax = std::max(pmax, act[a].p_end);
+            ok = ok && act[a].uniform;
+        }
+        if (ok && pmax >= 256 && pmax <= F2_N / 2) {
+            Fft2Voices vv;
+            std::memset(&vv, 0, sizeof(vv));
+            for (int a = 0; a < nact; a++) {
+                int rc = ensure_fft2(e, act[a].ir0);
+                if (!rc) rc = ensure_fft2(e, act[a].ir1);
+                if (rc) return rc;
+                vv.h0[a] = act[a].ir0->d_H2;
+                vv.h1[a] = act[a].ir1->d_H2;
+                vv.g[a] = act[a].ugain;
+            }
+            vv.n = nact;
+            const int chunk_t = F2_N - pmax + 1;
+            const dim3 grid(MC_NB, (T + chunk_t - 1) / chunk_t);
+            if (e->stash_chunks < grid.y) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (e->d_stash) (void)hipFree(e->d_stash);
+                e->d_stash = nullptr;
+                HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 4 * F2_N));
+                e->stash_chunks = grid.y;
+            }
+            hipLaunchKernelGGL(k_mac_fft, grid, dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc,
+                               e->Tcap, e->d_stash);
+            mo->ysrc = e->d_Yc;
+            mo->sk = e->Tcap;
+            mo->stt = 1;
+            mo->nsum = 1;
+            mo->sc = 0;
+            mo->swept = pmax;
+            mo->lvl = -1;  // marks the second-level transform in the kernel statistics
+            return MC_OK;
+        }
+    }
     int lvl = 0;
     if (mo->resident && e->ffa_levels > 0 && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0) {
         int pmin = 1 << 30;
@@ -1003,7 +1064,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 e->kev_n++;
                 e->ks.resident = mo.resident ? 1 : 0;
                 e->ks.partitions = (uint32_t)mo.swept;
-                e->ks.fast_levels = (uint32_t)mo.lvl;
+                e->ks.fast_levels = mo.lvl < 0 ? 255u : (uint32_t)mo.lvl;  // 255 = second-level transform
             }
             if (piped) {  // the inverse transforms wait for this MAC on the post stream; the engine's stream moves on
                 HIP_TRY(hipEventRecord(e->ev_mac[par][h], e->stream));
@@ -1538,6 +1599,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
+    if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
@@ -1566,12 +1628,15 @@ void mc_destroy(mc_engine* e) {
         for (int l = 0; l < 3; l++)
             if (e->irs[i].d_Hp[l]) (void)hipFree(e->irs[i].d_Hp[l]);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
+        if (e->irs[i].d_H2) (void)hipFree(e->irs[i].d_H2);
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H16) (void)hipFree(e->irs[i].d_H16);
     (void)hipFree(e->d_fdl);
     (void)hipFree(e->d_slotgain);
     (void)hipFree(e->d_fdl16);
+    (void)hipFree(e->d_stash);
     if (e->post_stream) (void)hipStreamSynchronize(e->post_stream);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(e->d_Ybuf[i]);

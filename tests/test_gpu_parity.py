@@ -1236,6 +1236,7 @@ def test_fast_fir_form_of_the_resident_mac(oracle_mod, gpu_lib, monkeypatch, lev
 
     def run(no_ffa):
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0" if no_ffa else str(levels))
+        monkeypatch.setenv("MCCONV_FFT2", "0")  # this test is about the fast-FIR MAC
         c = _conv(fftSize=n_ref, max_batch=max(sizes))
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
@@ -1314,3 +1315,50 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
             c.close()
     assert rms(outs[0]) > 1e-3
     assert np.array_equal(outs[0], outs[1]), f"rms difference {rms(outs[0] - outs[1]):.3e}"
+
+
+@pytest.mark.parametrize("n_ref,taps", [(131072, (88200, 80000)), (524288, (441000, 400000))], ids=["P345", "P1723"])
+def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch, n_ref, taps):
+    """Long batches whose window carries one set of gains skip the partition MAC: per bin the sum over partitions is
+    a convolution along the block axis, done as one circular convolution with a 16384-point transform per chunk of
+    blocks (k_mac_fft) against the IRs' transformed partition sequences.  Same output as the direct MAC and as the
+    oracle; batches start at an odd block, one is not a multiple of anything, one is longer than a chunk."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    sizes = [3, 1200, 4098, 15000 if n_ref == 131072 else 4096]
+    nb = sum(sizes)
+    x = make_input(nb * 256)
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
+    p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
+
+    def run(direct):
+        monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")
+        monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
+        c = _conv(fftSize=n_ref, max_batch=max(sizes))
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        out = np.zeros((2, nb * 256), np.float32)
+        o = 0
+        c.enable_kernel_timing(True)
+        for n in sizes:
+            s = slice(o * 256, (o + n) * 256)
+            out[:, s] = c.process(x[0, s], x[1, s])
+            o += n
+        ks = c.kernel_stats()
+        c.close()
+        return out, ks
+
+    fast, ks_fast = run(False)
+    direct, ks_direct = run(True)
+    assert ks_fast["fast_levels"] == 255 and ks_direct["fast_levels"] == 0
+    assert rms(fast - direct) <= 2e-6, f"second-level transform vs direct MAC: {rms(fast - direct):.3e}"
+    assert rms(fast - direct) > 0
+    nchk = min(nb, 6000 if n_ref == 131072 else 1500)
+    o = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        o.prepare(i, ir)
+    apply_params(o, p0, p1, True)
+    want = o.process(x[0, : nchk * 256], x[1, : nchk * 256])
+    err = rms(fast[:, : nchk * 256] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
