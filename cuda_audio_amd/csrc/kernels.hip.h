@@ -1852,6 +1852,14 @@ __device__ __forceinline__ void f2_inverse(float2* s, const float2* t_lo, const 
     __syncthreads();
 }
 
+// The forward transform leaves frequency f at position rev4(f) (its seven base-4 digits reversed).  Position of
+// frequency -f: used for bin 0, where the spectrum of conj(z) is needed: FFT(conj z)[f] = conj(FFT(z)[-f]).
+__device__ __forceinline__ int f2_rev4(int x) {
+    int r = (int)(__brev((unsigned)x) >> 18);             // 14 bits reversed
+    return ((r & 0x2AAA) >> 1) | ((r & 0x1555) << 1);     // bits inside each base-4 digit back in order
+}
+__device__ __forceinline__ int f2_mirror(int p) { return f2_rev4((F2_N - f2_rev4(p)) & (F2_N - 1)); }
+
 // Second-level spectra of an IR: for channel c (0 = L, 1 = R) and row r (bins 0 .. 255, row 256 = bin 0's h2)
 // the forward transform of the zero-padded partition sequence, digit-reversed order:
 // out[(c * 257 + r) * F2_N + i].   grid = (257, 2), block = 1024.
@@ -1887,7 +1895,7 @@ struct Fft2Voices {
 
 // grid = (256 bins, chunks), block = 1024.  Chunk c covers output blocks [c * chunk_t, ...) of the batch;
 // taps = partitions swept (>= every voice's), chunk_t + taps - 1 <= F2_N.
-// stash: [(chunk * 256 + bin) * 4 + k][F2_N] scratch: the transformed input sequences, re-read by the two product passes.
+// stash: [(chunk * 256 + bin) * 2 + i][F2_N] scratch: the transformed input sequences, re-read by the two product passes.
 __global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
                                                         int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap,
                                                         float2* __restrict__ stash) {
@@ -1897,12 +1905,10 @@ __global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict
     const int bin = blockIdx.x, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
     const float4* fk = fdl + (size_t)bin * ring;
     const int sb = slot0 + t_c0 - (taps - 1);
-    float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 4 * F2_N;
+    float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 2 * F2_N;
     f2_tables(t_lo, t_hi);
-    // transforms, in the order {x1, conj x1 (bin 0), x2, conj x2 (bin 0)}, parked in the stash
-    const int nvar = bin == 0 ? 2 : 1, nseq = 2 * nvar;
-    for (int q = 0; q < nseq; q++) {
-        const int i = q / nvar, var = q - i * nvar;
+    // transforms of x1 and x2, parked in the stash
+    for (int i = 0; i < 2; i++) {
         __syncthreads();  // the previous round's readers of s are done (also orders the tables)
         float2 v[R];
 #pragma unroll
@@ -1912,7 +1918,6 @@ __global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict
             if (n < L) {
                 const float4 x = fk[(sb + n) & (ring - 1)];
                 v[r] = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
-                if (var) v[r].y = -v[r].y;
             }
         }
 #pragma unroll
@@ -1920,32 +1925,49 @@ __global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict
         __syncthreads();
         f2_forward(s, t_lo, t_hi);
 #pragma unroll
-        for (int r = 0; r < R; r++) my[(size_t)q * F2_N + threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
+        for (int r = 0; r < R; r++) my[(size_t)i * F2_N + threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
     }
-    // per output channel: Y_c = sum over sequences and voices of gain * spectrum * IR spectrum, inverse transform,
-    // the valid part of the circle (its first taps - 1 outputs are discarded) to Yc
+    // Y_c = sum over sequences and voices of gain * spectrum * IR spectrum for both output channels in one sweep over
+    // the stash (L goes to LDS, R waits in registers), then per channel the inverse transform and the valid part of
+    // the circle (its first taps - 1 outputs are discarded) to Yc
+    __syncthreads();  // every thread's stash writes are visible to the workgroup (bin 0 reads mirrored entries)
+    float2 accR[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int idx = threadIdx.x + F2_THREADS * r;
+        float2 aL = make_float2(0.f, 0.f), aR = aL;
+        for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
+            const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
+            float2 S;
+            if (var) {
+                S = my[(size_t)i * F2_N + f2_mirror(idx)];
+                S.y = -S.y;
+            } else {
+                S = my[(size_t)i * F2_N + idx];
+            }
+            const size_t row = (size_t)(var ? 256 : bin) * F2_N + idx;
+#pragma unroll
+            for (int vi = 0; vi < MC_MAXV; vi++) {
+                if (vi >= vv.n) break;
+                const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
+                const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
+                const float2 pl = f2_mul(S, h[row]), pr = f2_mul(S, h[row + (size_t)257 * F2_N]);
+                aL.x = fmaf(gl, pl.x, aL.x);
+                aL.y = fmaf(gl, pl.y, aL.y);
+                aR.x = fmaf(gr, pr.x, aR.x);
+                aR.y = fmaf(gr, pr.y, aR.y);
+            }
+        }
+        s[F2_P(idx)] = aL;
+        accR[r] = aR;
+        if ((r & 3) == 3) asm volatile("" ::: "memory");  // four entries' loads in flight at a time: bounds the registers
+    }
     const float sc = 1.0f / (float)F2_N;
     for (int c = 0; c < 2; c++) {
-        __syncthreads();  // the previous pass's readers of s are done
-#pragma unroll 4
-        for (int r = 0; r < R; r++) {
-            const int idx = threadIdx.x + F2_THREADS * r;
-            float2 acc = make_float2(0.f, 0.f);
-            for (int q = 0; q < nseq; q++) {
-                const int i = q / nvar, var = q - i * nvar;
-                const float2 S = my[(size_t)q * F2_N + idx];
-                const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N + idx;
+        if (c == 1) {
+            __syncthreads();  // the readers of Y_L are done
 #pragma unroll
-                for (int vi = 0; vi < MC_MAXV; vi++) {
-                    if (vi >= vv.n) break;
-                    const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
-                    const float g = c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w);
-                    const float2 p = f2_mul(S, h[row]);
-                    acc.x = fmaf(g, p.x, acc.x);
-                    acc.y = fmaf(g, p.y, acc.y);
-                }
-            }
-            s[F2_P(idx)] = acc;
+            for (int r = 0; r < R; r++) s[F2_P(threadIdx.x + F2_THREADS * r)] = accR[r];
         }
         __syncthreads();
         f2_inverse(s, t_lo, t_hi);

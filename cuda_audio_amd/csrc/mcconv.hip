@@ -731,7 +731,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 if (e->d_stash) (void)hipFree(e->d_stash);
                 e->d_stash = nullptr;
-                HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 4 * F2_N));
+                HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 2 * F2_N));
                 e->stash_chunks = grid.y;
             }
             hipLaunchKernelGGL(k_mac_fft, grid, dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc,
