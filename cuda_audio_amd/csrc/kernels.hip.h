@@ -1893,49 +1893,51 @@ struct Fft2Voices {
     float4 g[MC_MAXV];          // {L<-in1, L<-in2, R<-in1, R<-in2}
 };
 
-// grid = (256 bins, chunks), block = 1024.  Chunk c covers output blocks [c * chunk_t, ...) of the batch;
-// taps = partitions swept (>= every voice's), chunk_t + taps - 1 <= F2_N.
-// stash: [(chunk * 256 + bin) * 2 + i][F2_N] scratch: the transformed input sequences, re-read by the two product passes.
-__global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
-                                                        int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap,
-                                                        float2* __restrict__ stash) {
+// The second-level transform runs as two kernels so that each workgroup holds one sequence and nothing else
+// (both are register-bound at 1024 threads):
+//   k_f2_fwd : grid (256 bins, chunks, 2 inputs): window of input i -> forward transform -> stash
+//   k_f2_prod: grid (256 bins, chunks, 2 channels): sum over inputs and voices of gain * spectrum * IR spectrum ->
+//              inverse transform -> the valid part of the circle (its first taps - 1 outputs are discarded) to Yc
+// Chunk c covers output blocks [c * chunk_t, ...) of the batch; taps = partitions swept (>= every voice's),
+// chunk_t + taps - 1 <= F2_N.  stash: [(chunk * 256 + bin) * 2 + i][F2_N].
+__global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                       int taps, float2* __restrict__ stash) {
     __shared__ float2 s[F2_LDS];
     __shared__ float2 t_lo[128], t_hi[128];
     constexpr int R = F2_N / F2_THREADS;
-    const int bin = blockIdx.x, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+    const int bin = blockIdx.x, i = blockIdx.z, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
     const float4* fk = fdl + (size_t)bin * ring;
     const int sb = slot0 + t_c0 - (taps - 1);
-    float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 2 * F2_N;
     f2_tables(t_lo, t_hi);
-    // transforms of x1 and x2, parked in the stash
-    for (int i = 0; i < 2; i++) {
-        __syncthreads();  // the previous round's readers of s are done (also orders the tables)
-        float2 v[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int n = threadIdx.x + F2_THREADS * r;
-            v[r] = make_float2(0.f, 0.f);
-            if (n < L) {
-                const float4 x = fk[(sb + n) & (ring - 1)];
-                v[r] = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) s[F2_P(threadIdx.x + F2_THREADS * r)] = v[r];
-        __syncthreads();
-        f2_forward(s, t_lo, t_hi);
-#pragma unroll
-        for (int r = 0; r < R; r++) my[(size_t)i * F2_N + threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
-    }
-    // Y_c = sum over sequences and voices of gain * spectrum * IR spectrum for both output channels in one sweep over
-    // the stash (L goes to LDS, R waits in registers), then per channel the inverse transform and the valid part of
-    // the circle (its first taps - 1 outputs are discarded) to Yc
-    __syncthreads();  // every thread's stash writes are visible to the workgroup (bin 0 reads mirrored entries)
-    float2 accR[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        const int n = threadIdx.x + F2_THREADS * r;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < L) {
+            const float4 x = fk[(sb + n) & (ring - 1)];
+            v = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
+        }
+        s[F2_P(n)] = v;
+    }
+    __syncthreads();
+    f2_forward(s, t_lo, t_hi);
+    float2* my = stash + (((size_t)blockIdx.y * MC_NB + bin) * 2 + i) * F2_N;
+#pragma unroll
+    for (int r = 0; r < R; r++) my[threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
+}
+
+__global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict__ stash, int T, int chunk_t, int taps, Fft2Voices vv,
+                                                        float4* __restrict__ Yc, int ycap) {
+    __shared__ float2 s[F2_LDS];
+    __shared__ float2 t_lo[128], t_hi[128];
+    constexpr int R = F2_N / F2_THREADS;
+    const int bin = blockIdx.x, c = blockIdx.z, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0);
+    const float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 2 * F2_N;
+    f2_tables(t_lo, t_hi);
+#pragma unroll 4
+    for (int r = 0; r < R; r++) {
         const int idx = threadIdx.x + F2_THREADS * r;
-        float2 aL = make_float2(0.f, 0.f), aR = aL;
+        float2 acc = make_float2(0.f, 0.f);
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
             float2 S;
@@ -1945,36 +1947,25 @@ __global__ __launch_bounds__(F2_THREADS) void k_mac_fft(const float4* __restrict
             } else {
                 S = my[(size_t)i * F2_N + idx];
             }
-            const size_t row = (size_t)(var ? 256 : bin) * F2_N + idx;
+            const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N + idx;
 #pragma unroll
             for (int vi = 0; vi < MC_MAXV; vi++) {
                 if (vi >= vv.n) break;
                 const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
-                const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
-                const float2 pl = f2_mul(S, h[row]), pr = f2_mul(S, h[row + (size_t)257 * F2_N]);
-                aL.x = fmaf(gl, pl.x, aL.x);
-                aL.y = fmaf(gl, pl.y, aL.y);
-                aR.x = fmaf(gr, pr.x, aR.x);
-                aR.y = fmaf(gr, pr.y, aR.y);
+                const float g = c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w);
+                const float2 p = f2_mul(S, h[row]);
+                acc.x = fmaf(g, p.x, acc.x);
+                acc.y = fmaf(g, p.y, acc.y);
             }
         }
-        s[F2_P(idx)] = aL;
-        accR[r] = aR;
-        if ((r & 3) == 3) asm volatile("" ::: "memory");  // four entries' loads in flight at a time: bounds the registers
+        s[F2_P(idx)] = acc;
     }
+    __syncthreads();
+    f2_inverse(s, t_lo, t_hi);
     const float sc = 1.0f / (float)F2_N;
-    for (int c = 0; c < 2; c++) {
-        if (c == 1) {
-            __syncthreads();  // the readers of Y_L are done
-#pragma unroll
-            for (int r = 0; r < R; r++) s[F2_P(threadIdx.x + F2_THREADS * r)] = accR[r];
-        }
-        __syncthreads();
-        f2_inverse(s, t_lo, t_hi);
-        float2* dst = reinterpret_cast<float2*>(Yc + (size_t)bin * ycap + t_c0) + c;  // .xy = Y_L, .zw = Y_R
-        for (int t = threadIdx.x; t < nout; t += F2_THREADS) {
-            const float2 y = s[F2_P(t + taps - 1)];
-            dst[2 * (size_t)t] = make_float2(y.x * sc, y.y * sc);
-        }
+    float2* dst = reinterpret_cast<float2*>(Yc + (size_t)bin * ycap + t_c0) + c;  // .xy = Y_L, .zw = Y_R
+    for (int t = threadIdx.x; t < nout; t += F2_THREADS) {
+        const float2 y = s[F2_P(t + taps - 1)];
+        dst[2 * (size_t)t] = make_float2(y.x * sc, y.y * sc);
     }
 }

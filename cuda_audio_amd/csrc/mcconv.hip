@@ -703,7 +703,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     // -1 .. T/2^L - 2, which covers the first T - 2^L blocks of the batch; the last 2^L blocks go through the
     // streaming kernel, so that no tile is spent on one extra output.
     // Long batches whose window carries one set of gains: the convolution along the block axis as a circular
-    // convolution per (bin, chunk of blocks) with a second-level transform of length F2_N (k_mac_fft); the IRs'
+    // convolution per (bin, chunk of blocks) with a second-level transform of length F2_N (k_f2_fwd, k_f2_prod); the IRs'
     // partition sequences are transformed once (k_fft2_ir).  O(log) instead of O(P) work per output block.
     if (mo->resident && e->fft2 && !per_slot_gains && !e->half && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0 &&
         T >= 2048) {
@@ -734,8 +734,10 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 2 * F2_N));
                 e->stash_chunks = grid.y;
             }
-            hipLaunchKernelGGL(k_mac_fft, grid, dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc,
-                               e->Tcap, e->d_stash);
+            hipLaunchKernelGGL(k_f2_fwd, dim3(grid.x, grid.y, 2), dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t,
+                               pmax, e->d_stash);
+            hipLaunchKernelGGL(k_f2_prod, dim3(grid.x, grid.y, 2), dim3(F2_THREADS), 0, e->stream, e->d_stash, T, chunk_t, pmax, vv,
+                               e->d_Yc, e->Tcap);
             mo->ysrc = e->d_Yc;
             mo->sk = e->Tcap;
             mo->stt = 1;

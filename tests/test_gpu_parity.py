@@ -1321,7 +1321,7 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
 def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch, n_ref, taps):
     """Long batches whose window carries one set of gains skip the partition MAC: per bin the sum over partitions is
     a convolution along the block axis, done as one circular convolution with a 16384-point transform per chunk of
-    blocks (k_mac_fft) against the IRs' transformed partition sequences.  Same output as the direct MAC and as the
+    blocks (k_f2_fwd, k_f2_prod) against the IRs' transformed partition sequences.  Same output as the direct MAC and as the
     oracle; batches start at an odd block, one is not a multiple of anything, one is longer than a chunk."""
     from cuda_audio_amd.synth import make_input, make_ir
 
