@@ -1895,17 +1895,28 @@ struct Fft2Voices {
 
 // The second-level transform runs as two kernels so that each workgroup holds one sequence and nothing else
 // (both are register-bound at 1024 threads):
-//   k_f2_fwd : grid (256 bins, chunks, 2 inputs): window of input i -> forward transform -> stash
-//   k_f2_prod: grid (256 bins, chunks, 2 channels): sum over inputs and voices of gain * spectrum * IR spectrum ->
+//   k_f2_fwd : grid 256 bins x chunks x 2 inputs: window of input i -> forward transform -> stash
+//   k_f2_prod: grid 256 bins x chunks x 2 channels: sum over inputs and voices of gain * spectrum * IR spectrum ->
 //              inverse transform -> the valid part of the circle (its first taps - 1 outputs are discarded) to Yc
 // Chunk c covers output blocks [c * chunk_t, ...) of the batch; taps = partitions swept (>= every voice's),
 // chunk_t + taps - 1 <= F2_N.  stash: [(chunk * 256 + bin) * 2 + i][F2_N].
+// Both grids are 1-D: the two workgroups of a (bin, chunk) - the two inputs, or the two output channels - read the
+// same delay-line window / the same stash entries, so they get block ids 8 apart: same XCD (id mod 8), dispatched
+// together, and the second reader finds the data in that XCD's L2.
+__device__ __forceinline__ void f2_decode(int id, int& bin, int& chunk, int& z) {
+    const int g = id >> 4, w = id & 15;
+    z = w >> 3;
+    bin = ((g & 31) << 3) + (w & 7);
+    chunk = g >> 5;
+}
 __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
                                                        int taps, float2* __restrict__ stash) {
     __shared__ float2 s[F2_LDS];
     __shared__ float2 t_lo[128], t_hi[128];
     constexpr int R = F2_N / F2_THREADS;
-    const int bin = blockIdx.x, i = blockIdx.z, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+    int bin, chunk, i;
+    f2_decode(blockIdx.x, bin, chunk, i);
+    const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
     const float4* fk = fdl + (size_t)bin * ring;
     const int sb = slot0 + t_c0 - (taps - 1);
     f2_tables(t_lo, t_hi);
@@ -1921,7 +1932,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict_
     }
     __syncthreads();
     f2_forward(s, t_lo, t_hi);
-    float2* my = stash + (((size_t)blockIdx.y * MC_NB + bin) * 2 + i) * F2_N;
+    float2* my = stash + (((size_t)chunk * MC_NB + bin) * 2 + i) * F2_N;
 #pragma unroll
     for (int r = 0; r < R; r++) my[threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
 }
@@ -1931,8 +1942,10 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
     __shared__ float2 s[F2_LDS];
     __shared__ float2 t_lo[128], t_hi[128];
     constexpr int R = F2_N / F2_THREADS;
-    const int bin = blockIdx.x, c = blockIdx.z, t_c0 = blockIdx.y * chunk_t, nout = min(chunk_t, T - t_c0);
-    const float2* my = stash + ((size_t)blockIdx.y * MC_NB + bin) * 2 * F2_N;
+    int bin, chunk, c;
+    f2_decode(blockIdx.x, bin, chunk, c);
+    const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0);
+    const float2* my = stash + ((size_t)chunk * MC_NB + bin) * 2 * F2_N;
     f2_tables(t_lo, t_hi);
 #pragma unroll 4
     for (int r = 0; r < R; r++) {

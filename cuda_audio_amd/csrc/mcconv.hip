@@ -734,9 +734,9 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 2 * F2_N));
                 e->stash_chunks = grid.y;
             }
-            hipLaunchKernelGGL(k_f2_fwd, dim3(grid.x, grid.y, 2), dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t,
+            hipLaunchKernelGGL(k_f2_fwd, dim3(grid.x * grid.y * 2), dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t,
                                pmax, e->d_stash);
-            hipLaunchKernelGGL(k_f2_prod, dim3(grid.x, grid.y, 2), dim3(F2_THREADS), 0, e->stream, e->d_stash, T, chunk_t, pmax, vv,
+            hipLaunchKernelGGL(k_f2_prod, dim3(grid.x * grid.y * 2), dim3(F2_THREADS), 0, e->stream, e->d_stash, T, chunk_t, pmax, vv,
                                e->d_Yc, e->Tcap);
             mo->ysrc = e->d_Yc;
             mo->sk = e->Tcap;

@@ -46,10 +46,15 @@ def main(tag, mode, dominant):
         lines.append(f"| {k[:60]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | "
                      f"{'' if f is None else round(f, 1)} | {'' if w is None else round(w, 1)} |")
     def pick(d):
-        for k, v in d.items():
-            if dominant in k:
-                return v
-        return None
+        # "a+b": the dominant work is split over several kernels; their traffic adds up
+        tot, found = 0.0, False
+        for name in dominant.split("+"):
+            for k, v in d.items():
+                if name in k:
+                    tot += v
+                    found = True
+                    break
+        return tot if found else None
 
     f = pick(pmc.get("FETCH_SIZE", {}))
     w = pick(pmc.get("WRITE_SIZE", {}))
