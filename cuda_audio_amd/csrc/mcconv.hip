@@ -684,6 +684,19 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
                            (int)((b0 + (uint64_t)mo.main_n) & (uint64_t)(e->sr - 1)), e->d_tw);
 }
 
+// Will launch_mac_batch take the second-level transform for this batch?
+bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T) {
+    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || per_slot_gains || e->cfg.part_begin || e->cfg.part_end || nact <= 0 ||
+        T < 2048)
+        return false;
+    int pmax = 0;
+    for (int a = 0; a < nact; a++) {
+        pmax = std::max(pmax, act[a].p_end);
+        if (!act[a].uniform) return false;
+    }
+    return pmax >= 256 && pmax <= F2_N / 2;
+}
+
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
 // per_slot_gains: the batch's blocks (or the window) do not share one set of gains.
 int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T, int slot0, MacOut* mo) {
@@ -705,15 +718,10 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     // Long batches whose window carries one set of gains: the convolution along the block axis as a circular
     // convolution per (bin, chunk of blocks) with a second-level transform of length F2_N (k_f2_fwd, k_f2_prod); the IRs'
     // partition sequences are transformed once (k_fft2_ir).  O(log) instead of O(P) work per output block.
-    if (mo->resident && e->fft2 && !per_slot_gains && !e->half && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0 &&
-        T >= 2048) {
+    if (fft2_applies(e, act, nact, per_slot_gains, T)) {
         int pmax = 0;
-        bool ok = true;
-        for (int a = 0; a < nact; a++) {
-            pmax = std::max(pmax, act[a].p_end);
-            ok = ok && act[a].uniform;
-        }
-        if (ok && pmax >= 256 && pmax <= F2_N / 2) {
+        for (int a = 0; a < nact; a++) pmax = std::max(pmax, act[a].p_end);
+        {
             Fft2Voices vv;
             std::memset(&vv, 0, sizeof(vv));
             for (int a = 0; a < nact; a++) {
@@ -1047,8 +1055,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
             for (int a = 0; a < st.nact; a++)
                 if (e->gain_change_block[st.act[a].v] + (uint64_t)st.act[a].p_end + (uint64_t)halo > e->t_front) per_slot = true;
         // K2 + K3.  The reach-back blocks run as their own short launch (for <= 33 blocks the streaming kernel), so
-        // that the slice itself fills whole 256-block tiles of the resident kernel.
-        const int parts[2][2] = {{0, halo}, {halo, count}};
+        // that the slice itself fills whole 256-block tiles of the resident kernel - unless the second-level
+        // transform takes the batch, which has no tiles: then the window is one launch.
+        const bool whole = halo > 0 && fft2_applies(e, st.act, st.nact, per_slot, halo + count);
+        const int parts[2][2] = {{0, whole ? 0 : halo}, {whole ? 0 : halo, whole ? halo + count : count}};
         for (int h = 0; h < 2; h++) {
             const int off = parts[h][0], n = parts[h][1];
             if (n <= 0) continue;
