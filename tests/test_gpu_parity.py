@@ -1326,6 +1326,8 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
     from cuda_audio_amd.synth import make_input, make_ir
 
     sizes = [3, 1200, 4098, 15000 if n_ref == 131072 else 4096]
+    if n_ref == 131072:
+        sizes += [4096, 4096]  # a gain change before the first of these: that batch must take the per-slot-gain MAC
     nb = sum(sizes)
     x = make_input(nb * 256)
     irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
@@ -1341,12 +1343,19 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
         out = np.zeros((2, nb * 256), np.float32)
         o = 0
         c.enable_kernel_timing(True)
-        for n in sizes:
+        levels = []
+        for k, n in enumerate(sizes):
+            if k == 4:
+                c.cc[1].value.update(wet=0.3, panWet=-0.5)
+                c.cc[0].value.level = 0.8
             s = slice(o * 256, (o + n) * 256)
             out[:, s] = c.process(x[0, s], x[1, s])
+            levels.append(c.kernel_stats()["fast_levels"])
             o += n
         ks = c.kernel_stats()
         c.close()
+        if not direct and len(sizes) > 4:
+            assert levels[3] == 255 and levels[4] == 0 and levels[5] == 255, levels
         return out, ks
 
     fast, ks_fast = run(False)
