@@ -1932,9 +1932,13 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict_
     }
     __syncthreads();
     f2_forward(s, t_lo, t_hi);
-    float2* my = stash + (((size_t)chunk * MC_NB + bin) * 2 + i) * F2_N;
+    float4* my = reinterpret_cast<float4*>(stash + (((size_t)chunk * MC_NB + bin) * 2 + i) * F2_N);
 #pragma unroll
-    for (int r = 0; r < R; r++) my[threadIdx.x + F2_THREADS * r] = s[F2_P(threadIdx.x + F2_THREADS * r)];
+    for (int r = 0; r < R / 2; r++) {  // 16 bytes per lane: entries 2j, 2j + 1
+        const int j = threadIdx.x + F2_THREADS * r;
+        const float2 a = s[F2_P(2 * j)], b = s[F2_P(2 * j + 1)];
+        my[j] = make_float4(a.x, a.y, b.x, b.y);
+    }
 }
 
 __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict__ stash, int T, int chunk_t, int taps, Fft2Voices vv,
@@ -1947,31 +1951,39 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
     const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0);
     const float2* my = stash + ((size_t)chunk * MC_NB + bin) * 2 * F2_N;
     f2_tables(t_lo, t_hi);
-#pragma unroll 4
-    for (int r = 0; r < R; r++) {
-        const int idx = threadIdx.x + F2_THREADS * r;
-        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll 2
+    for (int r = 0; r < R / 2; r++) {  // entries 2j, 2j + 1 per lane: 16-byte loads of the stash and the IR spectra
+        const int j = threadIdx.x + F2_THREADS * r, idx = 2 * j;
+        float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0;
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
-            float2 S;
+            float2 S0, S1;
             if (var) {
-                S = my[(size_t)i * F2_N + f2_mirror(idx)];
-                S.y = -S.y;
+                S0 = my[(size_t)i * F2_N + f2_mirror(idx)];
+                S1 = my[(size_t)i * F2_N + f2_mirror(idx + 1)];
+                S0.y = -S0.y;
+                S1.y = -S1.y;
             } else {
-                S = my[(size_t)i * F2_N + idx];
+                const float4 S = reinterpret_cast<const float4*>(my + (size_t)i * F2_N)[j];
+                S0 = make_float2(S.x, S.y);
+                S1 = make_float2(S.z, S.w);
             }
-            const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N + idx;
+            const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N;
 #pragma unroll
             for (int vi = 0; vi < MC_MAXV; vi++) {
                 if (vi >= vv.n) break;
                 const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
                 const float g = c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w);
-                const float2 p = f2_mul(S, h[row]);
-                acc.x = fmaf(g, p.x, acc.x);
-                acc.y = fmaf(g, p.y, acc.y);
+                const float4 H = reinterpret_cast<const float4*>(h + row)[j];
+                const float2 p0 = f2_mul(S0, make_float2(H.x, H.y)), p1 = f2_mul(S1, make_float2(H.z, H.w));
+                acc0.x = fmaf(g, p0.x, acc0.x);
+                acc0.y = fmaf(g, p0.y, acc0.y);
+                acc1.x = fmaf(g, p1.x, acc1.x);
+                acc1.y = fmaf(g, p1.y, acc1.y);
             }
         }
-        s[F2_P(idx)] = acc;
+        s[F2_P(idx)] = acc0;
+        s[F2_P(idx + 1)] = acc1;
     }
     __syncthreads();
     f2_inverse(s, t_lo, t_hi);
