@@ -1903,36 +1903,57 @@ struct Fft2Voices {
 // Both grids are 1-D: the two workgroups of a (bin, chunk) - the two inputs, or the two output channels - read the
 // same delay-line window / the same stash entries, so they get block ids 8 apart: same XCD (id mod 8), dispatched
 // together, and the second reader finds the data in that XCD's L2.
-__device__ __forceinline__ void f2_decode(int id, int& bin, int& chunk, int& z) {
-    const int g = id >> 4, w = id & 15;
+// Sequences per (bin, chunk): uniform gains - the 2 inputs (gains applied in the product); per-slot gains - for
+// every voice v and path (c, i) the sequence gain_v,c,i(slot) * X_i(slot): nseq = 4 * voices, index v * 4 + c * 2 + i.
+__device__ __forceinline__ void f2_decode(int id, int nz, int& bin, int& chunk, int& z) {
+    const int g = id / (8 * nz), w = id - g * 8 * nz;  // nz workgroups per (bin, chunk), 8 bins per group
     z = w >> 3;
     bin = ((g & 31) << 3) + (w & 7);
     chunk = g >> 5;
 }
+struct Fft2Gains {
+    const float4* row[MC_MAXV];  // per-slot gain table of each voice (null: uniform gains, nseq = 2)
+};
+
 __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
-                                                       int taps, float2* __restrict__ stash) {
+                                                       int taps, float2* __restrict__ stash, int nseq, Fft2Gains gg) {
     __shared__ float2 s[F2_LDS];
     __shared__ float2 t_lo[128], t_hi[128];
     constexpr int R = F2_N / F2_THREADS;
-    int bin, chunk, i;
-    f2_decode(blockIdx.x, bin, chunk, i);
+    int bin, chunk, z;
+    f2_decode(blockIdx.x, nseq, bin, chunk, z);
     const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
     const float4* fk = fdl + (size_t)bin * ring;
     const int sb = slot0 + t_c0 - (taps - 1);
+    // uniform gains: z = input; per-slot gains: z = voice * 4 + channel * 2 + input
+    const int i = z & 1, path = z & 3, v = z >> 2;
+    const float4* grow = nullptr;
+    if (nseq > 2) {
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++)
+            if (vi == v) grow = gg.row[vi];
+    }
     f2_tables(t_lo, t_hi);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int n = threadIdx.x + F2_THREADS * r;
-        float2 v = make_float2(0.f, 0.f);
+        float2 val = make_float2(0.f, 0.f);
         if (n < L) {
-            const float4 x = fk[(sb + n) & (ring - 1)];
-            v = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
+            const int slot = (sb + n) & (ring - 1);
+            const float4 x = fk[slot];
+            val = i == 0 ? make_float2(x.x, x.y) : make_float2(x.z, x.w);
+            if (grow) {
+                const float4 g4 = grow[slot];
+                const float g = path == 0 ? g4.x : (path == 1 ? g4.y : (path == 2 ? g4.z : g4.w));
+                val.x *= g;
+                val.y *= g;
+            }
         }
-        s[F2_P(n)] = v;
+        s[F2_P(n)] = val;
     }
     __syncthreads();
     f2_forward(s, t_lo, t_hi);
-    float4* my = reinterpret_cast<float4*>(stash + (((size_t)chunk * MC_NB + bin) * 2 + i) * F2_N);
+    float4* my = reinterpret_cast<float4*>(stash + (((size_t)chunk * MC_NB + bin) * nseq + z) * F2_N);
 #pragma unroll
     for (int r = 0; r < R / 2; r++) {  // 16 bytes per lane: entries 2j, 2j + 1
         const int j = threadIdx.x + F2_THREADS * r;
@@ -1942,14 +1963,15 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict_
 }
 
 __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict__ stash, int T, int chunk_t, int taps, Fft2Voices vv,
-                                                        float4* __restrict__ Yc, int ycap) {
+                                                        float4* __restrict__ Yc, int ycap, int nseq) {
     __shared__ float2 s[F2_LDS];
     __shared__ float2 t_lo[128], t_hi[128];
     constexpr int R = F2_N / F2_THREADS;
     int bin, chunk, c;
-    f2_decode(blockIdx.x, bin, chunk, c);
+    f2_decode(blockIdx.x, 2, bin, chunk, c);
     const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0);
-    const float2* my = stash + ((size_t)chunk * MC_NB + bin) * 2 * F2_N;
+    const float2* my = stash + ((size_t)chunk * MC_NB + bin) * nseq * F2_N;
+    const bool per_slot = nseq > 2;  // the stash holds gain-weighted sequences per voice and path
     f2_tables(t_lo, t_hi);
 #pragma unroll 2
     for (int r = 0; r < R / 2; r++) {  // entries 2j, 2j + 1 per lane: 16-byte loads of the stash and the IR spectra
@@ -1957,23 +1979,24 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
         float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0;
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
-            float2 S0, S1;
-            if (var) {
-                S0 = my[(size_t)i * F2_N + f2_mirror(idx)];
-                S1 = my[(size_t)i * F2_N + f2_mirror(idx + 1)];
-                S0.y = -S0.y;
-                S1.y = -S1.y;
-            } else {
-                const float4 S = reinterpret_cast<const float4*>(my + (size_t)i * F2_N)[j];
-                S0 = make_float2(S.x, S.y);
-                S1 = make_float2(S.z, S.w);
-            }
             const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N;
 #pragma unroll
             for (int vi = 0; vi < MC_MAXV; vi++) {
                 if (vi >= vv.n) break;
+                const float2* sq = my + (size_t)(per_slot ? vi * 4 + c * 2 + i : i) * F2_N;
+                float2 S0, S1;
+                if (var) {
+                    S0 = sq[f2_mirror(idx)];
+                    S1 = sq[f2_mirror(idx + 1)];
+                    S0.y = -S0.y;
+                    S1.y = -S1.y;
+                } else {
+                    const float4 S = reinterpret_cast<const float4*>(sq)[j];
+                    S0 = make_float2(S.x, S.y);
+                    S1 = make_float2(S.z, S.w);
+                }
                 const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
-                const float g = c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w);
+                const float g = per_slot ? 1.0f : (c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w));
                 const float4 H = reinterpret_cast<const float4*>(h + row)[j];
                 const float2 p0 = f2_mul(S0, make_float2(H.x, H.y)), p1 = f2_mul(S1, make_float2(H.z, H.w));
                 acc0.x = fmaf(g, p0.x, acc0.x);

@@ -88,7 +88,7 @@ struct mc_engine {
     bool half = false;
     float4* d_Yc = nullptr;  // [256][Tcap] partition sums combined from the fast-FIR components
     float2* d_stash = nullptr;  // second-level transform: spectra parked between the transforms and the products
-    size_t stash_chunks = 0;
+    size_t stash_chunks = 0;  // capacity of d_stash in sequences per bin (chunks x sequences per chunk)
     // Pipelined batches (mc_config.pipeline): the inverse transforms and the post stage of batch k run on a second
     // stream under the MAC of batch k + 1.  Scratch that both touch is double-buffered by batch parity.
     bool pipelined = false;
@@ -686,14 +686,12 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
 
 // Will launch_mac_batch take the second-level transform for this batch?
 bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T) {
-    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || per_slot_gains || e->cfg.part_begin || e->cfg.part_end || nact <= 0 ||
+    (void)per_slot_gains;  // both gain layouts are handled (uniform: 2 sequences per bin; per slot: 4 per voice)
+    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || e->cfg.part_begin || e->cfg.part_end || nact <= 0 ||
         T < 768)  // measured crossover with the direct MAC: ~600 blocks (0.095 ms whatever the batch length)
         return false;
     int pmax = 0;
-    for (int a = 0; a < nact; a++) {
-        pmax = std::max(pmax, act[a].p_end);
-        if (!act[a].uniform) return false;
-    }
+    for (int a = 0; a < nact; a++) pmax = std::max(pmax, act[a].p_end);
     return pmax >= 256 && pmax <= F2_N / 2;
 }
 
@@ -733,19 +731,29 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 vv.g[a] = act[a].ugain;
             }
             vv.n = nact;
+            // one set of gains over the whole window: transform the two inputs and weight the products; otherwise
+            // transform gain(slot) x input for every voice and path
+            bool per_slot = per_slot_gains;
+            for (int a = 0; a < nact; a++) per_slot = per_slot || !act[a].uniform;
+            const int nseq = per_slot ? 4 * nact : 2;
+            Fft2Gains gg;
+            std::memset(&gg, 0, sizeof(gg));
+            if (per_slot)
+                for (int a = 0; a < nact; a++) gg.row[a] = e->d_slotgain + (size_t)act[a].v * e->ring;
             const int chunk_t = F2_N - pmax + 1;
             const dim3 grid(MC_NB, (T + chunk_t - 1) / chunk_t);
-            if (e->stash_chunks < grid.y) {
+            const size_t need = (size_t)grid.y * nseq;
+            if (e->stash_chunks < need) {
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 if (e->d_stash) (void)hipFree(e->d_stash);
                 e->d_stash = nullptr;
-                HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * (size_t)grid.y * MC_NB * 2 * F2_N));
-                e->stash_chunks = grid.y;
+                HIP_TRY(hipMalloc(&e->d_stash, sizeof(float2) * need * MC_NB * F2_N));
+                e->stash_chunks = need;
             }
-            hipLaunchKernelGGL(k_f2_fwd, dim3(grid.x * grid.y * 2), dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t,
-                               pmax, e->d_stash);
+            hipLaunchKernelGGL(k_f2_fwd, dim3(grid.x * grid.y * nseq), dim3(F2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T,
+                               chunk_t, pmax, e->d_stash, nseq, gg);
             hipLaunchKernelGGL(k_f2_prod, dim3(grid.x * grid.y * 2), dim3(F2_THREADS), 0, e->stream, e->d_stash, T, chunk_t, pmax, vv,
-                               e->d_Yc, e->Tcap);
+                               e->d_Yc, e->Tcap, nseq);
             mo->ysrc = e->d_Yc;
             mo->sk = e->Tcap;
             mo->stt = 1;

@@ -1319,18 +1319,20 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
 
 @pytest.mark.parametrize("n_ref,taps", [(131072, (88200, 80000)), (524288, (441000, 400000))], ids=["P345", "P1723"])
 def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch, n_ref, taps):
-    """Long batches whose window carries one set of gains skip the partition MAC: per bin the sum over partitions is
-    a convolution along the block axis, done as one circular convolution with a 16384-point transform per chunk of
-    blocks (k_f2_fwd, k_f2_prod) against the IRs' transformed partition sequences.  Same output as the direct MAC and as the
-    oracle; batches start at an odd block, one is not a multiple of anything, one is longer than a chunk."""
+    """Long batches skip the partition MAC: per bin the sum over partitions is a convolution along the block axis,
+    done as one circular convolution with a 16384-point transform per chunk of blocks (k_f2_fwd, k_f2_prod) against
+    the IRs' transformed partition sequences - of the two inputs when the window carries one set of gains, of
+    gain(slot) x input per voice and path when it does not (cold-start ramp, a gain change).  Same output as the
+    direct MAC and as the oracle; batches start at an odd block, one is not a multiple of anything, one is longer
+    than a chunk."""
     from cuda_audio_amd.synth import make_input, make_ir
 
     sizes = [3, 1200, 4098, 15000 if n_ref == 131072 else 4096]
     if n_ref == 131072:
-        sizes += [4096, 4096]  # a gain change before the first of these: that batch must take the per-slot-gain MAC
+        sizes += [4096, 4096]  # a gain change before the first of these: its window carries two sets of gains
     nb = sum(sizes)
     x = make_input(nb * 256)
-    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)] + [make_ir(taps[0] - 7000, seed=99, norm=0.02)]
     p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
 
     def run(direct):
@@ -1348,14 +1350,16 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
             if k == 4:
                 c.cc[1].value.update(wet=0.3, panWet=-0.5)
                 c.cc[0].value.level = 0.8
+            if k == 5:
+                c.cc[0].value.update(select=2, vsteps=100)  # two voices with per-slot gains in the last batch
             s = slice(o * 256, (o + n) * 256)
             out[:, s] = c.process(x[0, s], x[1, s])
             levels.append(c.kernel_stats()["fast_levels"])
             o += n
         ks = c.kernel_stats()
         c.close()
-        if not direct and len(sizes) > 4:
-            assert levels[3] == 255 and levels[4] == 0 and levels[5] == 255, levels
+        if not direct:  # every batch of >= 768 blocks: cold-start ramp and gain change included (per-slot-gain sequences)
+            assert all(lv == 255 for lv, n in zip(levels, sizes) if n >= 768), levels
         return out, ks
 
     fast, ks_fast = run(False)
