@@ -958,83 +958,137 @@ __device__ __forceinline__ void write_history(const TailDrop& td, int64_t tau, i
 // mix (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
 // conv.cu:89-100, 126-140, 411-451).  One thread per output frame.
 // ---------------------------------------------------------------------------
+// wet sample u of this engine when it is not the thread's own: from the segment ring when no older than win0 (the
+// first sample whose segments this call has computed), else from the wet ring
+__device__ __forceinline__ float2 wet_at(const float* __restrict__ seg, int sr, const float* __restrict__ wet, int wr, int64_t u,
+                                         int64_t win0) {
+    if (u >= win0) return batch_wet(seg, sr, u >> 8, (int)(u & 255));
+    if (u >= 0) return make_float2(wet[(size_t)(u & (wr - 1))], wet[(size_t)wr + (u & (wr - 1))]);
+    return make_float2(0.f, 0.f);
+}
+
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
                                               float* __restrict__ wet, int wr, const double* __restrict__ cring, int rc,
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
-                                              int first, int64_t win0, int64_t predelay, int64_t n_ref, int compat, TailDrop td,
-                                              int pm, Retired ret, unsigned* __restrict__ done_flag, unsigned seq,
+                                              int first, int count, int64_t win0, int64_t predelay, int64_t n_ref, int compat,
+                                              TailDrop td, int pm, Retired ret, unsigned* __restrict__ done_flag, unsigned seq,
                                               unsigned* __restrict__ done_ctr) {
     // done_flag (mapped host memory) != null: outL/outR are host buffers and the last workgroup to finish
     // publishes `seq` once every workgroup's output is visible to the host (one JACK period of 512 / 1024 frames)
-    // T blocks in the batch starting at absolute block tabs0; this launch finishes blocks first .. first + gridDim.x - 1
+    // T blocks in the batch starting at absolute block tabs0; this launch finishes blocks first .. first + count - 1
     // of it (the whole batch unless the engine runs block-sliced) into outL/outR, which start at block `first`.
     // win0: first absolute sample whose segments this call has computed.
     // pm = blocks per reference call (JACK period / 256): Q1/Q2/Q8 windows are measured from the call start
-    const int t = first + blockIdx.x, m = threadIdx.x;
-    const int64_t i = (int64_t)t * MC_B + m;
-    const int64_t o = (int64_t)blockIdx.x * MC_B + m;
-    const int64_t tau0 = tabs0 * MC_B;
-    const int64_t tau = tau0 + i;
-    const int64_t u = tau - predelay;
-    float wl, wr_;
-    if (lin) {  // shards: the sum over ranks of k_ola's output (predelay and retired partition sums included)
-        wl = lin[i];
-        wr_ = lin[(size_t)T * MC_B + i];
-    } else {
-        const float2 w = delayed_wet(seg, sr, wet, wr, tau, win0, predelay);
-        wl = w.x;
-        wr_ = w.y;
-        if (tau < ret.end) {
-            const float2 r = retired_at(ret.mac, ret.rr, tau);
-            wl += r.x;
-            wr_ += r.y;
-        }
-    }
-    if (tau < ret.end) {
-        const float2 r = retired_at(ret.fix, ret.rr, tau);
-        wl += r.x;
-        wr_ += r.y;
-    }
-    double cl = 0.0, cr = 0.0;
-    if (compat && u >= 0) {
-        // calls q (pm blocks each) of the live epoch with predelay <= tau - q*period < n_ref (shift by predelay, cut
-        // at n_ref: Q8); prefix sums are per block, so a call ends at block (q + 1) pm - 1
-        const int64_t thi = ((u >> 8) / pm + 1) * pm - 1;
-        const int64_t v = tau - n_ref;
-        int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
-        if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
-        if (thi > tlo) {
-            const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
-            double d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
-            if (tlo >= 0) {
-                const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
-                d0 -= b[0];
-                d1 -= b[1];
-                q0 -= b[2];
-                q1 -= b[3];
+    // One wave per block, four consecutive frames per lane (16-byte loads and stores); grid = ceil(count / 4).
+    const int tb = blockIdx.x * 4 + (threadIdx.x >> 6);  // block within the slice
+    if (tb < count) {
+        const int t = first + tb, m0 = (threadIdx.x & 63) * 4;
+        const int64_t i0 = (int64_t)t * MC_B + m0;
+        const int64_t o0 = (int64_t)tb * MC_B + m0;
+        const int64_t tau0 = tabs0 * MC_B;
+        const int64_t tau_0 = tau0 + i0;
+        float wl[4], wr_[4];
+        if (lin) {  // shards: the sum over ranks of k_ola's output (predelay and retired partition sums included)
+            const float4 a = *reinterpret_cast<const float4*>(lin + i0), b = *reinterpret_cast<const float4*>(lin + (size_t)T * MC_B + i0);
+            wl[0] = a.x, wl[1] = a.y, wl[2] = a.z, wl[3] = a.w;
+            wr_[0] = b.x, wr_[1] = b.y, wr_[2] = b.z, wr_[3] = b.w;
+        } else {
+            // own samples: this block's first half + the previous block's second half, both channels
+            const int64_t b = tau_0 >> 8;
+            const float* cur = seg + (size_t)(b & (sr - 1)) * 2 * FFT_N;
+            const float* prv = seg + (size_t)((b + sr - 1) & (sr - 1)) * 2 * FFT_N;
+            const float4 cl4 = *reinterpret_cast<const float4*>(cur + m0), pl4 = *reinterpret_cast<const float4*>(prv + MC_B + m0);
+            const float4 cr4 = *reinterpret_cast<const float4*>(cur + FFT_N + m0);
+            const float4 pr4 = *reinterpret_cast<const float4*>(prv + FFT_N + MC_B + m0);
+            const float4 ol = make_float4(cl4.x + pl4.x, cl4.y + pl4.y, cl4.z + pl4.z, cl4.w + pl4.w);
+            const float4 orr = make_float4(cr4.x + pr4.x, cr4.y + pr4.y, cr4.z + pr4.z, cr4.w + pr4.w);
+            *reinterpret_cast<float4*>(wet + (size_t)(tau_0 & (wr - 1))) = ol;
+            *reinterpret_cast<float4*>(wet + (size_t)wr + (tau_0 & (wr - 1))) = orr;
+            wl[0] = ol.x, wl[1] = ol.y, wl[2] = ol.z, wl[3] = ol.w;
+            wr_[0] = orr.x, wr_[1] = orr.y, wr_[2] = orr.z, wr_[3] = orr.w;
+            if (predelay != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float2 w = wet_at(seg, sr, wet, wr, tau_0 + k - predelay, win0);
+                    wl[k] = w.x;
+                    wr_[k] = w.y;
+                }
             }
-            const double sg = (u & 1) ? -1.0 : 1.0;
-            cl = d0 + sg * q0;
-            cr = d1 + sg * q1;
+            if (tau_0 < ret.end) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (tau_0 + k < ret.end) {
+                        const float2 r = retired_at(ret.mac, ret.rr, tau_0 + k);
+                        wl[k] += r.x;
+                        wr_[k] += r.y;
+                    }
+            }
         }
+        if (tau_0 < ret.end) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (tau_0 + k < ret.end) {
+                    const float2 r = retired_at(ret.fix, ret.rr, tau_0 + k);
+                    wl[k] += r.x;
+                    wr_[k] += r.y;
+                }
+        }
+        const BlockParams& bp = ptab[(int64_t)t * pstride];
+        const float4 x1 = *reinterpret_cast<const float4*>(in1 + i0), x2 = *reinterpret_cast<const float4*>(in2 + i0);
+        const float x1a[4] = {x1.x, x1.y, x1.z, x1.w}, x2a[4] = {x2.x, x2.y, x2.z, x2.w};
+        float ol_[4], or_[4];
+        double d0 = 0, d1 = 0, q0 = 0, q1 = 0;
+        int64_t have_thi = -2, have_tlo = -2;  // the window of the previous frame: four frames usually share one
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t tau = tau_0 + k, u = tau - predelay;
+            double cl = 0.0, cr = 0.0;
+            if (compat && u >= 0) {
+                // calls q (pm blocks each) of the live epoch with predelay <= tau - q*period < n_ref (shift by predelay,
+                // cut at n_ref: Q8); prefix sums are per block, so a call ends at block (q + 1) pm - 1
+                const int64_t thi = ((u >> 8) / pm + 1) * pm - 1;
+                const int64_t v = tau - n_ref;
+                int64_t tlo = v >= 0 ? ((v >> 8) / pm + 1) * pm - 1 : -1;
+                if (tlo < ret.b0 - 1) tlo = ret.b0 - 1;
+                if (thi > tlo) {
+                    if (thi != have_thi || tlo != have_tlo) {
+                        const double* a = cring + (size_t)(thi & (rc - 1)) * 4;
+                        d0 = a[0], d1 = a[1], q0 = a[2], q1 = a[3];
+                        if (tlo >= 0) {
+                            const double* b = cring + (size_t)(tlo & (rc - 1)) * 4;
+                            d0 -= b[0];
+                            d1 -= b[1];
+                            q0 -= b[2];
+                            q1 -= b[3];
+                        }
+                        have_thi = thi;
+                        have_tlo = tlo;
+                    }
+                    const double sg = (u & 1) ? -1.0 : 1.0;
+                    cl = d0 + sg * q0;
+                    cr = d1 + sg * q1;
+                }
+            }
+            float a = wl[k], b = wr_[k];
+            if (td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
+                float dl, dr;
+                tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
+                a -= dl;
+                b -= dr;
+            }
+            const float vl = fminf(fmaxf((float)((double)a + cl), -1.f), 1.f);
+            const float vr = fminf(fmaxf((float)((double)b + cr), -1.f), 1.f);
+            ol_[k] = vl + x1a[k] * bp.d[0] + x2a[k] * bp.d[1];
+            or_[k] = vr + x1a[k] * bp.d[2] + x2a[k] * bp.d[3];
+        }
+        *reinterpret_cast<float4*>(outL + o0) = make_float4(ol_[0], ol_[1], ol_[2], ol_[3]);
+        *reinterpret_cast<float4*>(outR + o0) = make_float4(or_[0], or_[1], or_[2], or_[3]);
     }
-    const BlockParams& bp = ptab[(int64_t)t * pstride];
-    const float x1 = in1[i], x2 = in2[i];
-    if (td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
-        float dl, dr;
-        tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
-        wl -= dl;
-        wr_ -= dr;
-    }
-    float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
-    float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
-    outL[o] = vl + x1 * bp.d[0] + x2 * bp.d[1];
-    outR[o] = vr + x1 * bp.d[2] + x2 * bp.d[3];
     if (done_flag) {
         __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
-        if (m == 0) {
+        if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this workgroup's output is on the host
             const unsigned old = atomicAdd(done_ctr, 1u);
             if (old == gridDim.x - 1) {

@@ -130,7 +130,8 @@ int mc_handle_cc(mc_engine *e, int half, const uint8_t ccmap[8], uint8_t control
 int mc_process(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nframes);
 /* nblocks consecutive periods, host buffers of nblocks*256 floats */
 int mc_process_batch(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nblocks);
-/* the same with device-resident buffers; asynchronous on the engine's stream */
+/* the same with device-resident buffers (16-byte aligned, as hipMalloc and block-granular slices of it are);
+ * asynchronous on the engine's stream */
 int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,
                             uint64_t nblocks);
 /* Block-sliced operation - scaling batch throughput over GPUs without a data-path collective.  The output blocks
