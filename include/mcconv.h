@@ -97,8 +97,9 @@ typedef struct {
     double last_ms;
     uint32_t resident;      /* 1 = the last launch used the resident (batch) kernel */
     uint32_t partitions;    /* partitions swept per block by the last launch */
-    uint32_t fast_levels;   /* fast-FIR levels of the last resident launch: it executed (3/4)^levels of the direct
-                               form's multiply-adds (0 = direct form) */
+    uint32_t fast_levels;   /* how the last long batch summed its partitions: 0 = direct-form MAC, 1..3 = fast-FIR form
+                               with that many nested levels ((3/4)^levels of the multiply-adds), 255 = second-level
+                               transform along the block axis instead of the MAC */
     uint32_t reserved;
 } mc_kernel_stats;
 
