@@ -466,29 +466,36 @@ def main():
     common = {"kernel": "k_mac_resident" if ks["resident"] else "k_mac_stream", "traffic": traffic,
               "kernel_avg_ms": round(kern_avg_ms, 5), "kernel_launches": ks["launches"], "blocks_per_launch": (ks["blocks"] // max(ks["launches"], 1)) if ks["launches"] else T,
               "flops_per_block": int(flops_per_block)}
-    if ks["resident"] and int(ks.get("fast_levels", 0)) == 255:
+    if ks["resident"] and int(ks.get("fast_levels", 0)) in (254, 255):
         # Second-level transform (k_f2_fwd + k_f2_prod): per (bin, chunk of blocks) one circular convolution of 16384 points.  Its
         # own compulsory traffic per launch: the delay-line window of both inputs, the IRs' second-level spectra (four
         # paths), the partition sums it writes; it is bound by memory (HBM / L2), not by arithmetic.
-        F2 = 16384
+        fused = int(ks["fast_levels"]) == 254
+        F2 = 8192 if fused else 16384
         Pq = int(ks["partitions"])
         blk = ks["blocks"] // max(ks["launches"], 1)
         nchunk = -(-blk // (F2 - Pq + 1))
-        # windows of 2 inputs + their transforms parked once and read by both channel passes + 4 paths of second-level
-        # spectra + the partition sums written
-        own_bytes = 256 * (2 * 8 * (blk + nchunk * (Pq - 1)) + (2 + 4) * 8 * F2 * nchunk + 4 * 8 * F2 * nchunk + 16 * blk)
+        if fused:
+            # one kernel, both inputs' spectra side by side in LDS: the window once (16 B per slot), 4 paths of
+            # second-level spectra per chunk, the partition sums written
+            own_bytes = 256 * (16 * (blk + nchunk * (Pq - 1)) + 4 * 8 * F2 * nchunk + 16 * blk)
+        else:
+            # windows of 2 inputs + their transforms parked once and read by both channel passes + 4 paths of
+            # second-level spectra + the partition sums written
+            own_bytes = 256 * (2 * 8 * (blk + nchunk * (Pq - 1)) + (2 + 4) * 8 * F2 * nchunk + 4 * 8 * F2 * nchunk + 16 * blk)
         own_gbs = own_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-        common["kernel"] = "k_f2_fwd + k_f2_prod"
+        common["kernel"] = "k_g2_mac" if fused else "k_f2_fwd + k_f2_prod"
         roofline = dict({"bound": "hbm", "achieved": round(own_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(own_gbs / HBM_PEAK_GBS, 4)}, **common)
         roofline["algorithmic_bytes_per_launch"] = own_bytes
         roofline["replaces"] = {"kernel": "partition x bin MAC (direct form)", "tflops_equivalent": round(achieved_tf, 2),
                                 "frac_of_fp32_peak": round(achieved_tf / FP32_PEAK_TFLOPS, 4), "hbm_equivalent": hbm_equiv}
         roofline["note"] = ("The batch's partition sums are computed by a second-level transform along the block axis instead of "
-                            "the partition x bin MAC: per bin one 16384-point circular convolution per chunk of blocks (radix-16/4 "
-                            "passes in 133 KB of LDS) against the IRs' transformed partition sequences. achieved = this kernel's "
-                            "own algorithmic bytes (delay-line window of 2 inputs, their transforms written once and read by both "
-                            "channel passes, second-level spectra of 4 paths, partition sums written) / time of the two kernels (HIP events on the launch stream); `replaces` prices the same launch as "
+                            "the partition x bin MAC: per bin one circular convolution per chunk of blocks (8192 points with both "
+                            "inputs' spectra side by side in 133 KB of LDS, k_g2_mac; 16384 points through a stash for long IRs "
+                            "and per-slot gains, k_f2_fwd + k_f2_prod) against the IRs' transformed partition sequences. "
+                            "achieved = the kernel's own algorithmic bytes (delay-line window, second-level spectra of 4 paths "
+                            "per chunk, partition sums written; the split form also its stash) / kernel time (HIP events on the launch stream); `replaces` prices the same launch as "
                             "the direct-form MAC it stands for (SURVEY 8(d) accounting). MCCONV_FFT2=0 runs the MAC kernel "
                             "(fast-FIR form), MCCONV_FFA_LEVELS=0 its direct form.")
     elif ks["resident"]:

@@ -2071,3 +2071,224 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
         dst[2 * (size_t)t] = make_float2(y.x * sc, y.y * sc);
     }
 }
+
+// ---------------------------------------------------------------------------
+// Second-level transform, fused form for uniform gains and IRs up to 2560
+// partitions: transforms of 8192 points, so that the spectra of BOTH input
+// sequences of a (bin, chunk) fit in LDS side by side (2 x 66.5 KB).  One
+// workgroup reads the delay-line window once (16 bytes per slot: both inputs),
+// transforms the two sequences in its two halves (512 threads each), forms
+// Y_L and Y_R in place (every thread owns its entries of both buffers), inverts
+// both and writes {Y_L, Y_R} as 16-byte entries.  No stash: per 8192-block launch
+// it moves the windows (41 MB), the second-level spectra (134 MB for two chunks)
+// and the sums (33 MB).
+// 8192 = 4^6 x 2: radix-16 passes with quarter lengths 2048/512, 128/32, 8/2,
+// then one radix-2 stage.  Position p after the forward transform holds
+// frequency rev(p): the six base-4 digits of p >> 1 reversed, plus (p & 1) << 12.
+// ---------------------------------------------------------------------------
+#define G2_N 8192
+#define G2_LDS (G2_N + G2_N / 64)
+#define G2_THREADS 1024
+
+__device__ __forceinline__ float2 g2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
+
+__device__ __forceinline__ void g2_tables(float2* t_lo, float2* t_hi) {  // w = exp(-2 pi i / 8192): w^k (128), w^(128 k) (64)
+    if (threadIdx.x < 192) {
+        const bool lo = threadIdx.x < 128;
+        const int k = lo ? threadIdx.x : threadIdx.x - 128;
+        float sn, cs;
+        sincospif((lo ? (float)k : (float)(128 * k)) * (-2.0f / (float)G2_N), &sn, &cs);
+        (lo ? t_lo : t_hi)[k] = make_float2(cs, sn);
+    }
+}
+
+// two consecutive radix-4 stages (quarter lengths 4 Q and Q) on the 16 elements pos0 + Q m of a thread; see f2_pair
+template <bool INV>
+__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
+    const int Q = 1 << lq;
+    const int step1 = G2_N >> (lq + 4), step2 = G2_N >> (lq + 2);
+    float2 a[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) a[m] = s[F2_P(pos0 + Q * m)];
+    if (!INV) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            f2_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            f2_tw3<false>(a[r + 4], a[r + 8], a[r + 12], g2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+        }
+        const float2 w = g2_tw(t_lo, t_hi, j0 * step2);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            f2_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            f2_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+        }
+    } else {
+        const float2 w = g2_tw(t_lo, t_hi, j0 * step2);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            f2_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            f2_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            f2_tw3<true>(a[r + 4], a[r + 8], a[r + 12], g2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            f2_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) s[F2_P(pos0 + Q * m)] = a[m];
+}
+
+// the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
+__device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = tt + 512 * r;
+        const float2 a = s[F2_P(2 * p)], b = s[F2_P(2 * p + 1)];
+        s[F2_P(2 * p)] = make_float2(a.x + b.x, a.y + b.y);
+        s[F2_P(2 * p + 1)] = make_float2(a.x - b.x, a.y - b.y);
+    }
+}
+
+// forward / inverse transform of the buffer this half of the workgroup (tt = thread within the half, 0..511) owns
+__device__ __forceinline__ void g2_forward(float2* s, const float2* t_lo, const float2* t_hi, int tt) {
+    g2_pair<false>(s, t_lo, t_hi, tt, tt, 9);  // quarter lengths 2048, 512
+    __syncthreads();
+    g2_pair<false>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31, 5);  // 128, 32
+    __syncthreads();
+    g2_pair<false>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);  // 8, 2
+    __syncthreads();
+    g2_pairs2(s, tt);
+    __syncthreads();
+}
+__device__ __forceinline__ void g2_inverse(float2* s, const float2* t_lo, const float2* t_hi, int tt) {
+    g2_pairs2(s, tt);
+    __syncthreads();
+    g2_pair<true>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);
+    __syncthreads();
+    g2_pair<true>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31, 5);
+    __syncthreads();
+    g2_pair<true>(s, t_lo, t_hi, tt, tt, 9);
+    __syncthreads();
+}
+
+// position <-> frequency of the forward transform's output order, and the position of frequency -f
+__device__ __forceinline__ int g2_rev6(int x) {  // six base-4 digits reversed (12 bits)
+    int r = (int)(__brev((unsigned)x) >> 20);
+    return ((r & 0xAAA) >> 1) | ((r & 0x555) << 1);
+}
+__device__ __forceinline__ int g2_mirror(int p) {
+    const int f = g2_rev6(p >> 1) | ((p & 1) << 12);
+    const int g = (G2_N - f) & (G2_N - 1);
+    return (g2_rev6(g & 4095) << 1) | (g >> 12);
+}
+
+// second-level spectra for the 8192-point form: out[(c * 257 + row) * G2_N + i]; grid (257, 1), both channels per workgroup
+__global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__ H, int pstride, int P, float2* __restrict__ out) {
+    __shared__ float2 s[2][G2_LDS];
+    __shared__ float2 t_lo[128], t_hi[64];
+    const int row = blockIdx.x, bin = row == 256 ? 0 : row;
+    const int c = threadIdx.x >> 9, tt = threadIdx.x & 511;
+    g2_tables(t_lo, t_hi);
+    for (int i = tt; i < G2_N; i += 512) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < P) {
+            const float4 h = H[(size_t)bin * pstride + i];
+            const float2 hc = c == 0 ? make_float2(h.x, h.y) : make_float2(h.z, h.w);
+            if (bin != 0)
+                v = hc;
+            else
+                v = make_float2(row == 0 ? 0.5f * (hc.x + hc.y) : 0.5f * (hc.x - hc.y), 0.f);
+        }
+        s[c][F2_P(i)] = v;
+    }
+    __syncthreads();
+    g2_forward(s[c], t_lo, t_hi, tt);
+    float2* dst = out + ((size_t)c * 257 + row) * G2_N;
+    for (int i = tt; i < G2_N; i += 512) dst[i] = s[c][F2_P(i)];
+}
+
+// grid = 256 bins x chunks, block = 1024 (two halves: input 1 / input 2, later Y_L / Y_R).
+// chunk_t + taps - 1 <= G2_N.
+__global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                       int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap) {
+    __shared__ float2 s[2][G2_LDS];
+    __shared__ float2 t_lo[128], t_hi[64];
+    const int bin = blockIdx.x & (MC_NB - 1), chunk = blockIdx.x >> 8;
+    const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+    const float4* fk = fdl + (size_t)bin * ring;
+    const int sb = slot0 + t_c0 - (taps - 1);
+    const int half = threadIdx.x >> 9, tt = threadIdx.x & 511;
+    g2_tables(t_lo, t_hi);
+    // the window, once: 16 bytes per slot carry both inputs
+#pragma unroll
+    for (int r = 0; r < G2_N / G2_THREADS; r++) {
+        const int n = threadIdx.x + G2_THREADS * r;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < L) x = fk[(sb + n) & (ring - 1)];
+        s[0][F2_P(n)] = make_float2(x.x, x.y);
+        s[1][F2_P(n)] = make_float2(x.z, x.w);
+    }
+    __syncthreads();
+    g2_forward(s[half], t_lo, t_hi, tt);
+    // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers
+    float2 yl[8], yr[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int j = threadIdx.x + G2_THREADS * r, idx = 2 * j;
+        float2 aL0 = make_float2(0.f, 0.f), aL1 = aL0, aR0 = aL0, aR1 = aL0;
+        for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
+            const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
+            float2 S0, S1;
+            if (var) {
+                S0 = s[i][F2_P(g2_mirror(idx))];
+                S1 = s[i][F2_P(g2_mirror(idx + 1))];
+                S0.y = -S0.y;
+                S1.y = -S1.y;
+            } else {
+                S0 = s[i][F2_P(idx)];
+                S1 = s[i][F2_P(idx + 1)];
+            }
+            const size_t row = (size_t)(var ? 256 : bin) * G2_N;
+#pragma unroll
+            for (int vi = 0; vi < MC_MAXV; vi++) {
+                if (vi >= vv.n) break;
+                const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
+                const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
+                const float4 HL = reinterpret_cast<const float4*>(h + row)[j];
+                const float4 HR = reinterpret_cast<const float4*>(h + row + (size_t)257 * G2_N)[j];
+                const float2 pl0 = f2_mul(S0, make_float2(HL.x, HL.y)), pl1 = f2_mul(S1, make_float2(HL.z, HL.w));
+                const float2 pr0 = f2_mul(S0, make_float2(HR.x, HR.y)), pr1 = f2_mul(S1, make_float2(HR.z, HR.w));
+                aL0.x = fmaf(gl, pl0.x, aL0.x);
+                aL0.y = fmaf(gl, pl0.y, aL0.y);
+                aL1.x = fmaf(gl, pl1.x, aL1.x);
+                aL1.y = fmaf(gl, pl1.y, aL1.y);
+                aR0.x = fmaf(gr, pr0.x, aR0.x);
+                aR0.y = fmaf(gr, pr0.y, aR0.y);
+                aR1.x = fmaf(gr, pr1.x, aR1.x);
+                aR1.y = fmaf(gr, pr1.y, aR1.y);
+            }
+        }
+        yl[2 * r] = aL0;
+        yl[2 * r + 1] = aL1;
+        yr[2 * r] = aR0;
+        yr[2 * r + 1] = aR1;
+    }
+    __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int idx = 2 * (threadIdx.x + G2_THREADS * r);
+        s[0][F2_P(idx)] = yl[2 * r];
+        s[0][F2_P(idx + 1)] = yl[2 * r + 1];
+        s[1][F2_P(idx)] = yr[2 * r];
+        s[1][F2_P(idx + 1)] = yr[2 * r + 1];
+    }
+    __syncthreads();
+    g2_inverse(s[half], t_lo, t_hi, tt);
+    const float sc = 1.0f / (float)G2_N;
+    float4* dst = Yc + (size_t)bin * ycap + t_c0;
+    for (int t = threadIdx.x; t < nout; t += G2_THREADS) {
+        const float2 a = s[0][F2_P(t + taps - 1)], b = s[1][F2_P(t + taps - 1)];
+        dst[t] = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc);
+    }
+}

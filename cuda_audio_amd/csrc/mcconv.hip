@@ -61,6 +61,8 @@ struct IrEntry {
     float4* d_Hp[3] = {nullptr, nullptr, nullptr};  // fast-FIR components of the partition sequence: 3 / 9 / 27 arrays
     float2* d_H2 = nullptr;  // second-level spectra [2 ch][257 rows][F2_N], built on first use (k_fft2_ir)
     bool h2_valid = false;
+    float2* d_G2 = nullptr;  // second-level spectra for the fused 8192-point form [2 ch][257 rows][G2_N]
+    bool g2_valid = false;
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -169,7 +171,8 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
-    bool fft2 = true;     // long uniform-gain batches: second-level transform along the block axis instead of the MAC
+    bool fft2 = true;     // long batches: second-level transform along the block axis instead of the MAC
+    bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
@@ -270,7 +273,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 
 // fast-FIR components of an IR's spectra (levels 1 and 2) for the resident MAC
 int build_polyphase(mc_engine* e, IrEntry& ir) {
-    ir.h2_valid = false;  // the spectra changed: the second-level spectra are rebuilt on next use
+    ir.h2_valid = ir.g2_valid = false;  // the spectra changed: the second-level spectra are rebuilt on next use
     if (e->half || e->Pstride < 128) return MC_OK;  // the fp16 MAC streams; small engines never use the fast form
     for (int lvl = 1; lvl <= 3; lvl++) {
         if ((e->Pstride >> lvl) < 32) break;
@@ -290,6 +293,16 @@ int ensure_fft2(mc_engine* e, const IrEntry* irc) {
     hipLaunchKernelGGL(k_fft2_ir, dim3(257, 2), dim3(F2_THREADS), 0, e->stream, ir.d_H, e->Pstride, std::min(ir.P, F2_N), ir.d_H2);
     HIP_TRY(hipGetLastError());
     ir.h2_valid = true;
+    return MC_OK;
+}
+
+int ensure_g2(mc_engine* e, const IrEntry* irc) {
+    IrEntry& ir = *const_cast<IrEntry*>(irc);
+    if (ir.g2_valid) return MC_OK;
+    if (!ir.d_G2) HIP_TRY(hipMalloc(&ir.d_G2, sizeof(float2) * (size_t)2 * 257 * G2_N));
+    hipLaunchKernelGGL(k_g2_ir, dim3(257), dim3(G2_THREADS), 0, e->stream, ir.d_H, e->Pstride, std::min(ir.P, G2_N), ir.d_G2);
+    HIP_TRY(hipGetLastError());
+    ir.g2_valid = true;
     return MC_OK;
 }
 
@@ -735,6 +748,28 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
             // transform gain(slot) x input for every voice and path
             bool per_slot = per_slot_gains;
             for (int a = 0; a < nact; a++) per_slot = per_slot || !act[a].uniform;
+            if (!per_slot && e->fft2_fused && pmax <= 2560) {
+                // fused form: both inputs' 8192-point spectra side by side in LDS, no stash (k_g2_mac)
+                for (int a = 0; a < nact; a++) {
+                    int rc = ensure_g2(e, act[a].ir0);
+                    if (!rc) rc = ensure_g2(e, act[a].ir1);
+                    if (rc) return rc;
+                    vv.h0[a] = act[a].ir0->d_G2;
+                    vv.h1[a] = act[a].ir1->d_G2;
+                }
+                const int chunk_t = G2_N - pmax + 1;
+                const int nch = (T + chunk_t - 1) / chunk_t;
+                hipLaunchKernelGGL(k_g2_mac, dim3(MC_NB * nch), dim3(G2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax,
+                                   vv, e->d_Yc, e->Tcap);
+                mo->ysrc = e->d_Yc;
+                mo->sk = e->Tcap;
+                mo->stt = 1;
+                mo->nsum = 1;
+                mo->sc = 0;
+                mo->swept = pmax;
+                mo->lvl = -2;  // second-level transform, fused form
+                return MC_OK;
+            }
             const int nseq = per_slot ? 4 * nact : 2;
             Fft2Gains gg;
             std::memset(&gg, 0, sizeof(gg));
@@ -1084,7 +1119,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 e->kev_n++;
                 e->ks.resident = mo.resident ? 1 : 0;
                 e->ks.partitions = (uint32_t)mo.swept;
-                e->ks.fast_levels = mo.lvl < 0 ? 255u : (uint32_t)mo.lvl;  // 255 = second-level transform
+                e->ks.fast_levels = mo.lvl == -2 ? 254u : (mo.lvl < 0 ? 255u : (uint32_t)mo.lvl);  // 255 / 254 = second-level transform
             }
             if (piped) {  // the inverse transforms wait for this MAC on the post stream; the engine's stream moves on
                 HIP_TRY(hipEventRecord(e->ev_mac[par][h], e->stream));
@@ -1620,6 +1655,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
+    if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
@@ -1649,6 +1685,8 @@ void mc_destroy(mc_engine* e) {
             if (e->irs[i].d_Hp[l]) (void)hipFree(e->irs[i].d_Hp[l]);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H2) (void)hipFree(e->irs[i].d_H2);
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
+        if (e->irs[i].d_G2) (void)hipFree(e->irs[i].d_G2);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
