@@ -2087,7 +2087,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 // frequency rev(p): the six base-4 digits of p >> 1 reversed, plus (p & 1) << 12.
 // ---------------------------------------------------------------------------
 #define G2_N 8192
-#define G2_LDS (G2_N + G2_N / 64)
+// one pad entry per 32 elements: the 8/2 pass puts consecutive lanes on consecutive 32-element groups (stride 33)
+#define G2_P(i) ((i) + ((i) >> 5))
+#define G2_LDS (G2_N + G2_N / 32)
 #define G2_THREADS 1024
 
 __device__ __forceinline__ float2 g2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
@@ -2109,7 +2111,7 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
     const int step1 = G2_N >> (lq + 4), step2 = G2_N >> (lq + 2);
     float2 a[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = s[F2_P(pos0 + Q * m)];
+    for (int m = 0; m < 16; m++) a[m] = s[G2_P(pos0 + Q * m)];
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -2136,7 +2138,7 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
         }
     }
 #pragma unroll
-    for (int m = 0; m < 16; m++) s[F2_P(pos0 + Q * m)] = a[m];
+    for (int m = 0; m < 16; m++) s[G2_P(pos0 + Q * m)] = a[m];
 }
 
 // the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
@@ -2144,9 +2146,9 @@ __device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int p = tt + 512 * r;
-        const float2 a = s[F2_P(2 * p)], b = s[F2_P(2 * p + 1)];
-        s[F2_P(2 * p)] = make_float2(a.x + b.x, a.y + b.y);
-        s[F2_P(2 * p + 1)] = make_float2(a.x - b.x, a.y - b.y);
+        const float2 a = s[G2_P(2 * p)], b = s[G2_P(2 * p + 1)];
+        s[G2_P(2 * p)] = make_float2(a.x + b.x, a.y + b.y);
+        s[G2_P(2 * p + 1)] = make_float2(a.x - b.x, a.y - b.y);
     }
 }
 
@@ -2200,12 +2202,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__
             else
                 v = make_float2(row == 0 ? 0.5f * (hc.x + hc.y) : 0.5f * (hc.x - hc.y), 0.f);
         }
-        s[c][F2_P(i)] = v;
+        s[c][G2_P(i)] = v;
     }
     __syncthreads();
     g2_forward(s[c], t_lo, t_hi, tt);
     float2* dst = out + ((size_t)c * 257 + row) * G2_N;
-    for (int i = tt; i < G2_N; i += 512) dst[i] = s[c][F2_P(i)];
+    for (int i = tt; i < G2_N; i += 512) dst[i] = s[c][G2_P(i)];
 }
 
 // grid = 256 bins x chunks, block = 1024 (two halves: input 1 / input 2, later Y_L / Y_R).
@@ -2226,8 +2228,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         const int n = threadIdx.x + G2_THREADS * r;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < L) x = fk[(sb + n) & (ring - 1)];
-        s[0][F2_P(n)] = make_float2(x.x, x.y);
-        s[1][F2_P(n)] = make_float2(x.z, x.w);
+        s[0][G2_P(n)] = make_float2(x.x, x.y);
+        s[1][G2_P(n)] = make_float2(x.z, x.w);
     }
     __syncthreads();
     g2_forward(s[half], t_lo, t_hi, tt);
@@ -2241,13 +2243,13 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
             float2 S0, S1;
             if (var) {
-                S0 = s[i][F2_P(g2_mirror(idx))];
-                S1 = s[i][F2_P(g2_mirror(idx + 1))];
+                S0 = s[i][G2_P(g2_mirror(idx))];
+                S1 = s[i][G2_P(g2_mirror(idx + 1))];
                 S0.y = -S0.y;
                 S1.y = -S1.y;
             } else {
-                S0 = s[i][F2_P(idx)];
-                S1 = s[i][F2_P(idx + 1)];
+                S0 = s[i][G2_P(idx)];
+                S1 = s[i][G2_P(idx + 1)];
             }
             const size_t row = (size_t)(var ? 256 : bin) * G2_N;
 #pragma unroll
@@ -2273,22 +2275,23 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         yl[2 * r + 1] = aL1;
         yr[2 * r] = aR0;
         yr[2 * r + 1] = aR1;
+        asm volatile("" ::: "memory");  // one group of loads in flight at a time: keeps the kernel free of spills
     }
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int idx = 2 * (threadIdx.x + G2_THREADS * r);
-        s[0][F2_P(idx)] = yl[2 * r];
-        s[0][F2_P(idx + 1)] = yl[2 * r + 1];
-        s[1][F2_P(idx)] = yr[2 * r];
-        s[1][F2_P(idx + 1)] = yr[2 * r + 1];
+        s[0][G2_P(idx)] = yl[2 * r];
+        s[0][G2_P(idx + 1)] = yl[2 * r + 1];
+        s[1][G2_P(idx)] = yr[2 * r];
+        s[1][G2_P(idx + 1)] = yr[2 * r + 1];
     }
     __syncthreads();
     g2_inverse(s[half], t_lo, t_hi, tt);
     const float sc = 1.0f / (float)G2_N;
     float4* dst = Yc + (size_t)bin * ycap + t_c0;
     for (int t = threadIdx.x; t < nout; t += G2_THREADS) {
-        const float2 a = s[0][F2_P(t + taps - 1)], b = s[1][F2_P(t + taps - 1)];
+        const float2 a = s[0][G2_P(t + taps - 1)], b = s[1][G2_P(t + taps - 1)];
         dst[t] = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc);
     }
 }
