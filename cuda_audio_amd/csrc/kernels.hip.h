@@ -35,6 +35,10 @@
 #define MC_MAXV 3    // voices (IR pairs) that may sound at once
 #define FWD_TILE 8   // blocks per workgroup of the forward / inverse transform kernels (2 per wave)
 #define FWD_TILE_LOG2 3
+#ifndef XF_WAVES
+#define XF_WAVES 8  // waves per workgroup of the forward / inverse transform kernels (FWD_TILE / XF_WAVES blocks each)
+#endif
+#define XF_THREADS (64 * XF_WAVES)
 
 // fp16 storage of a spectrum entry: four halves {a.re, a.im, b.re, b.im} in 8 bytes
 __device__ __forceinline__ uint2 pack_half4(float4 v, float scale) {
@@ -72,7 +76,7 @@ struct VoiceSums {
 // are the two "inputs", slot = partition index.
 // grid = ceil(T / 8), block = 256 (4 waves x 2 transforms each).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
+__global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
                                              int in_stride,     // floats between successive frames (1, or 2 for interleaved IR)
                                              int64_t n_frames,  // valid frames in in1/in2 (zero beyond)
                                              int T, float4* __restrict__ fdl, int ring, int slot0,
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
-    __shared__ float2 s_fft[4][FFT_WAVE_LDS];
+    __shared__ float2 s_fft[XF_WAVES][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
     load_twiddles(s_tw, g_tw);
     __syncthreads();
@@ -96,8 +100,9 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     const int tb0 = blockIdx.x * FWD_TILE;
     float2* lds = s_fft[wave];
     auto needed = [&](int t) { return (t >= need_a0 && t < need_a1) || t >= need_b0; };
-    for (int it = 0; it < FWD_TILE / 4; it++) {
-        const int tb = it * 4 + wave;  // block within tile
+    const bool vec_in = in_stride == 1 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+    for (int it = 0; it < FWD_TILE / XF_WAVES; it++) {
+        const int tb = it * XF_WAVES + wave;  // block within tile
         const int t = tb0 + tb;
         if (t < T && !needed(t)) {  // wave-uniform
             if (sums && lane == 0) sums[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,7 +112,24 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
         float2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = make_float2(0.f, 0.f);
-        if (t < T) {
+        if (t < T && vec_in && (int64_t)(t + 1) * MC_B <= n_frames) {
+            // whole block of contiguous frames: 16 bytes per lane and access, re-striped through the wave's LDS
+            const int64_t f = (int64_t)t * MC_B + 4 * lane;
+            const float4 a = *reinterpret_cast<const float4*>(in1 + f), b = *reinterpret_cast<const float4*>(in2 + f);
+            if (xhist) {  // input history for the Q8 pass of later calls
+                const size_t at = (size_t)((tabs0 * MC_B + f) & (xr - 1));
+                *reinterpret_cast<float4*>(xhist + at) = a;
+                *reinterpret_cast<float4*>(xhist + xr + at) = b;
+            }
+            lds[4 * lane] = make_float2(a.x, b.x);
+            lds[4 * lane + 1] = make_float2(a.y, b.y);
+            lds[4 * lane + 2] = make_float2(a.z, b.z);
+            lds[4 * lane + 3] = make_float2(a.w, b.w);
+            fft_sync<false>();
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = lds[lane + 64 * r];
+            fft_sync<false>();
+        } else if (t < T) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {  // n = lane + 64 r < 256: the block; 256..511 stay zero
                 int64_t f = (int64_t)t * MC_B + lane + 64 * r;
@@ -149,7 +171,7 @@ __global__ __launch_bounds__(256) void k_fwd(const float* __restrict__ in1, cons
     }
     __syncthreads();
     // transposed, coalesced store: 8 consecutive slots (128 B) per bin
-    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
+    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += XF_THREADS) {
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         if (t < T && needed(t)) {
@@ -642,15 +664,15 @@ __global__ __launch_bounds__(256) void k_ffa_combine(const float4* __restrict__ 
 // Y element (bin k, block t) = sum_{c<nsum} Ysrc[k*sk + t*st + c*sc].
 // seg[(seg0 + t) mod sr][ch][512].   grid = ceil(T/8), block = 256.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
+__global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                              int T, float* __restrict__ seg, int sr, int seg0,
                                              const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
-    __shared__ float2 s_fft[4][FFT_WAVE_LDS];
+    __shared__ float2 s_fft[XF_WAVES][FFT_WAVE_LDS];
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
     load_twiddles(s_tw, g_tw);
     const int tb0 = blockIdx.x * FWD_TILE;
-    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += 256) {
+    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += XF_THREADS) {
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -669,8 +691,8 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float2* lds = s_fft[wave];
-    for (int it = 0; it < FWD_TILE / 4; it++) {
-        const int tb = it * 4 + wave;
+    for (int it = 0; it < FWD_TILE / XF_WAVES; it++) {
+        const int tb = it * XF_WAVES + wave;
         const int t = tb0 + tb;
         float2 v[8];
 #pragma unroll
@@ -697,11 +719,11 @@ __global__ __launch_bounds__(256) void k_inv(const float4* __restrict__ Ysrc, in
             float* dst = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
             const float sc = 1.0f / FFT_N;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int n = lane + 64 * j;
-                float2 z = lds[n];
-                dst[n] = z.x * sc;
-                dst[FFT_N + n] = z.y * sc;
+            for (int j = 0; j < 2; j++) {  // 16 bytes per lane and store
+                const int n = 4 * lane + 256 * j;
+                const float2 z0 = lds[n], z1 = lds[n + 1], z2 = lds[n + 2], z3 = lds[n + 3];
+                *reinterpret_cast<float4*>(dst + n) = make_float4(z0.x * sc, z1.x * sc, z2.x * sc, z3.x * sc);
+                *reinterpret_cast<float4*>(dst + FFT_N + n) = make_float4(z0.y * sc, z1.y * sc, z2.y * sc, z3.y * sc);
             }
         }
         __syncthreads();

@@ -685,14 +685,14 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
             hipLaunchKernelGGL(k_ffa_combine<2>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
         else
             hipLaunchKernelGGL(k_ffa_combine<3>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, e->d_Yc, (int64_t)e->Tcap,
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, e->d_Yc, (int64_t)e->Tcap,
                            (int64_t)1, 1, (int64_t)0, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
     } else if (mo.main_n > 0) {
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, mo.ysrc, mo.sk, mo.stt, mo.nsum,
+        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, mo.ysrc, mo.sk, mo.stt, mo.nsum,
                            mo.sc, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
     }
     if (mo.tail_n > 0)
-        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, st, mo.tail_ysrc, mo.tail_sk,
+        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, mo.tail_ysrc, mo.tail_sk,
                            mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, e->d_seg, e->sr,
                            (int)((b0 + (uint64_t)mo.main_n) & (uint64_t)(e->sr - 1)), e->d_tw);
 }
@@ -979,7 +979,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         if (!(Tc >= e->stream_threshold && !e->half)) Tc = std::min(Tc, e->Tstream);
         const int slot0 = (int)(tv & (uint64_t)(e->ring - 1)), seg0 = (int)(tv & (uint64_t)(e->sr - 1));
         // silent blocks into the delay line (n_frames = 0: the inputs are never read)
-        hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, (const float*)nullptr,
+        hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
                            (int64_t)0, 0, Tc, Tc);
@@ -1084,7 +1084,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
 
     // K1: the blocks this engine can reach (all T unless block-sliced)
-    hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_in1, d_in2, 1,
+    hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
                        e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0);
     if (e->ktiming && e->kev_n == kEvPool) {
@@ -1780,7 +1780,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     hipError_t er = hipMemcpy(d_lr, lr, sizeof(float) * 2 * n, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemsetAsync(ir.d_H, 0, sizeof(float4) * (size_t)MC_NB * e->Pstride, e->stream);
     if (er == hipSuccess) {
-        hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(256), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
+        hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
                            (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P);
         er = hipGetLastError();
