@@ -2131,6 +2131,9 @@ template <bool INV>
 __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
     const int Q = 1 << lq;
     const int step1 = G2_N >> (lq + 4), step2 = G2_N >> (lq + 2);
+    // LDS addresses are recomputed in every pass: shared between the forward and the inverse transform they would stay
+    // live across the whole kernel and spill
+    asm volatile("" : "+v"(pos0), "+v"(j0));
     float2 a[16];
 #pragma unroll
     for (int m = 0; m < 16; m++) a[m] = s[G2_P(pos0 + Q * m)];
@@ -2165,6 +2168,7 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
 
 // the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
 __device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int p = tt + 512 * r;

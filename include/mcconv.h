@@ -58,7 +58,7 @@ typedef struct {
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint64_t n_ref;         /* the reference's fftSize (conv.h:52): IR truncation n_ref-1024
                                (conv.cu:239), Q1/Q2 window and 1/n_ref factors */
-    uint32_t max_batch;     /* largest nblocks accepted by the batch calls (1..131072; host-buffer calls <= 16384) */
+    uint32_t max_batch;     /* largest nblocks accepted by the batch calls (1..262144; host-buffer calls <= 16384) */
     uint32_t max_partitions;/* 0 = derive from n_ref: ceil((n_ref-1024)/256) */
     uint32_t compat;        /* 1 = bug-compatible with conv.cu (DC/Nyquist terms Q1/Q2);
                                0 = plain linear convolution */
