@@ -672,21 +672,28 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
     __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
     load_twiddles(s_tw, g_tw);
     const int tb0 = blockIdx.x * FWD_TILE;
-    for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += XF_THREADS) {
-        int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
-        int t = tb0 + tb;
-        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) {
-            const float4* src = Ysrc + (int64_t)k * sk + (int64_t)t * st;
-            for (int c = 0; c < nsum; c++) {
-                float4 a = src[c * sc];
-                y.x += a.x;
-                y.y += a.y;
-                y.z += a.z;
-                y.w += a.w;
+    {
+        constexpr int NR = MC_NB * FWD_TILE / XF_THREADS, KS = XF_THREADS / FWD_TILE;  // entries per thread, bins between them
+        const int tb = threadIdx.x & (FWD_TILE - 1), k0 = threadIdx.x >> FWD_TILE_LOG2;
+        const int t = tb0 + tb;
+        const float4* src = Ysrc + (int64_t)k0 * sk + (int64_t)t * st;
+        float4 y[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++)  // the first (usually only) term of all of the thread's bins in flight together
+            y[r] = t < T ? src[(int64_t)KS * r * sk] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T)
+            for (int c = 1; c < nsum; c++) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const float4 a = src[(int64_t)KS * r * sk + c * sc];
+                    y[r].x += a.x;
+                    y[r].y += a.y;
+                    y[r].z += a.z;
+                    y[r].w += a.w;
+                }
             }
-        }
-        s_tile[k][tb] = y;
+#pragma unroll
+        for (int r = 0; r < NR; r++) s_tile[k0 + KS * r][tb] = y[r];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -727,6 +734,114 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
             }
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3w: inverse transform + overlap-add straight into the wet ring (whole-batch
+// path; k_post then reads the ring instead of the segment ring, which saves the
+// 4 KB per block round trip through memory).  A workgroup finishes the 8 blocks
+// of its tile; a ninth wave repeats the inverse of the block before the tile
+// (its second half is the other addend of the tile's first block) - for the
+// first tile of a launch that half comes from the segment ring, where the last
+// block of every launch is kept in full for the next launch / call.
+// The transforms reuse the memory of the transposed tile (all nine waves have
+// their inputs in registers by then): 45.5 KB of LDS, three workgroups per CU.
+// Y element as in k_inv.  wet[ch][(tau0 + 256 t + m) mod wr].  grid = ceil(T/8), block = 576.
+// ---------------------------------------------------------------------------
+#define IW_WAVES (FWD_TILE + 1)
+#define IW_THREADS (64 * IW_WAVES)
+__global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
+                                                        int T, float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet,
+                                                        int wr, int64_t tau0, const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ __align__(16) float2 s_mem[IW_WAVES * FFT_WAVE_LDS];  // tile [256 bins][9 blocks] of float4, then 9 transforms
+    static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * IW_WAVES, "tile fits the transform buffers");
+    float4(*s_tile)[IW_WAVES] = reinterpret_cast<float4(*)[IW_WAVES]>(s_mem);
+    load_twiddles(s_tw, g_tw);
+    const int tb0 = blockIdx.x * FWD_TILE;
+    {
+        const int c = threadIdx.x % IW_WAVES, k0 = threadIdx.x / IW_WAVES;  // column c <-> block tb0 - 1 + c
+        const int t = tb0 - 1 + c;
+        const bool live = t >= 0 && t < T;
+        const float4* src = Ysrc + (int64_t)k0 * sk + (int64_t)t * st;
+        float4 y[MC_NB / 64];
+#pragma unroll
+        for (int r = 0; r < MC_NB / 64; r++)  // the first (usually only) term of all four bins in flight together
+            y[r] = live ? src[(int64_t)64 * r * sk] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+            for (int cc = 1; cc < nsum; cc++) {
+#pragma unroll
+                for (int r = 0; r < MC_NB / 64; r++) {
+                    const float4 a = src[(int64_t)64 * r * sk + cc * sc];
+                    y[r].x += a.x;
+                    y[r].y += a.y;
+                    y[r].z += a.z;
+                    y[r].w += a.w;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < MC_NB / 64; r++) s_tile[k0 + 64 * r][c] = y[r];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = tb0 - 1 + wave;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int n = lane + 64 * r;
+        float2 w;
+        if (n == 0) {
+            float4 y = s_tile[0][wave];
+            w = make_float2(y.x, y.z);  // DC of L, R
+        } else if (n == MC_B) {
+            float4 y = s_tile[0][wave];
+            w = make_float2(y.y, y.w);  // Nyquist of L, R
+        } else if (n < MC_B) {
+            float4 y = s_tile[n][wave];
+            w = make_float2(y.x - y.w, y.y + y.z);  // Y_L + j Y_R
+        } else {
+            float4 y = s_tile[FFT_N - n][wave];
+            w = make_float2(y.x + y.w, -y.y + y.z);  // conj(Y_L) + j conj(Y_R)
+        }
+        v[r] = w;
+    }
+    __syncthreads();  // the tile is in registers: its memory becomes the transform buffers
+    float2* lds = s_mem + wave * FFT_WAVE_LDS;
+    if (t >= 0 && t < T) {
+        fft512_wave<+1, false>(v, lds, s_tw, lane);
+    } else if (t < 0) {
+        // the block before the launch: its second half from the segment ring, in the transforms' scale (x 512, exact)
+        const float* prv = seg + (size_t)((seg0 + sr - 1) & (sr - 1)) * 2 * FFT_N;
+        const float4 a = *reinterpret_cast<const float4*>(prv + MC_B + 4 * lane);
+        const float4 b = *reinterpret_cast<const float4*>(prv + FFT_N + MC_B + 4 * lane);
+        const float up = (float)FFT_N;
+        lds[MC_B + 4 * lane] = make_float2(a.x * up, b.x * up);
+        lds[MC_B + 4 * lane + 1] = make_float2(a.y * up, b.y * up);
+        lds[MC_B + 4 * lane + 2] = make_float2(a.z * up, b.z * up);
+        lds[MC_B + 4 * lane + 3] = make_float2(a.w * up, b.w * up);
+    }
+    __syncthreads();
+    if (wave > 0 && t < T) {
+        const float scl = 1.0f / FFT_N;
+        const float2* prev = lds - FFT_WAVE_LDS + MC_B;
+        const int m0 = 4 * lane;
+        const float2 o0 = lds[m0], o1 = lds[m0 + 1], o2 = lds[m0 + 2], o3 = lds[m0 + 3];
+        const float2 p0 = prev[m0], p1 = prev[m0 + 1], p2 = prev[m0 + 2], p3 = prev[m0 + 3];
+        // (a + b) / 512 == a / 512 + b / 512 exactly: the same bits as overlap-adding scaled segments
+        const size_t at = (size_t)((tau0 + (int64_t)t * MC_B + m0) & (wr - 1));
+        *reinterpret_cast<float4*>(wet + at) = make_float4((o0.x + p0.x) * scl, (o1.x + p1.x) * scl, (o2.x + p2.x) * scl, (o3.x + p3.x) * scl);
+        *reinterpret_cast<float4*>(wet + wr + at) = make_float4((o0.y + p0.y) * scl, (o1.y + p1.y) * scl, (o2.y + p2.y) * scl, (o3.y + p3.y) * scl);
+        if (t == T - 1) {  // the launch's last block stays in the segment ring in full
+            float* dst = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int n = 4 * lane + 256 * j;
+                const float2 z0 = lds[n], z1 = lds[n + 1], z2 = lds[n + 2], z3 = lds[n + 3];
+                *reinterpret_cast<float4*>(dst + n) = make_float4(z0.x * scl, z1.x * scl, z2.x * scl, z3.x * scl);
+                *reinterpret_cast<float4*>(dst + FFT_N + n) = make_float4(z0.y * scl, z1.y * scl, z2.y * scl, z3.y * scl);
+            }
+        }
     }
 }
 
@@ -990,7 +1105,7 @@ __device__ __forceinline__ float2 wet_at(const float* __restrict__ seg, int sr, 
 }
 
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
-                                              float* __restrict__ wet, int wr, const double* __restrict__ cring, int rc,
+                                              float* wet, int wr, const double* __restrict__ cring, int rc,
                                               const BlockParams* __restrict__ ptab, int pstride,
                                               const float* __restrict__ in1, const float* __restrict__ in2,
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
@@ -1017,17 +1132,23 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
             wl[0] = a.x, wl[1] = a.y, wl[2] = a.z, wl[3] = a.w;
             wr_[0] = b.x, wr_[1] = b.y, wr_[2] = b.z, wr_[3] = b.w;
         } else {
-            // own samples: this block's first half + the previous block's second half, both channels
-            const int64_t b = tau_0 >> 8;
-            const float* cur = seg + (size_t)(b & (sr - 1)) * 2 * FFT_N;
-            const float* prv = seg + (size_t)((b + sr - 1) & (sr - 1)) * 2 * FFT_N;
-            const float4 cl4 = *reinterpret_cast<const float4*>(cur + m0), pl4 = *reinterpret_cast<const float4*>(prv + MC_B + m0);
-            const float4 cr4 = *reinterpret_cast<const float4*>(cur + FFT_N + m0);
-            const float4 pr4 = *reinterpret_cast<const float4*>(prv + FFT_N + MC_B + m0);
-            const float4 ol = make_float4(cl4.x + pl4.x, cl4.y + pl4.y, cl4.z + pl4.z, cl4.w + pl4.w);
-            const float4 orr = make_float4(cr4.x + pr4.x, cr4.y + pr4.y, cr4.z + pr4.z, cr4.w + pr4.w);
-            *reinterpret_cast<float4*>(wet + (size_t)(tau_0 & (wr - 1))) = ol;
-            *reinterpret_cast<float4*>(wet + (size_t)wr + (tau_0 & (wr - 1))) = orr;
+            float4 ol, orr;
+            if (!seg) {  // k_inv_wet has overlap-added the whole window into the wet ring (win0 = INT64_MAX)
+                ol = *reinterpret_cast<const float4*>(wet + (size_t)(tau_0 & (wr - 1)));
+                orr = *reinterpret_cast<const float4*>(wet + (size_t)wr + (tau_0 & (wr - 1)));
+            } else {
+                // own samples: this block's first half + the previous block's second half, both channels
+                const int64_t b = tau_0 >> 8;
+                const float* cur = seg + (size_t)(b & (sr - 1)) * 2 * FFT_N;
+                const float* prv = seg + (size_t)((b + sr - 1) & (sr - 1)) * 2 * FFT_N;
+                const float4 cl4 = *reinterpret_cast<const float4*>(cur + m0), pl4 = *reinterpret_cast<const float4*>(prv + MC_B + m0);
+                const float4 cr4 = *reinterpret_cast<const float4*>(cur + FFT_N + m0);
+                const float4 pr4 = *reinterpret_cast<const float4*>(prv + FFT_N + MC_B + m0);
+                ol = make_float4(cl4.x + pl4.x, cl4.y + pl4.y, cl4.z + pl4.z, cl4.w + pl4.w);
+                orr = make_float4(cr4.x + pr4.x, cr4.y + pr4.y, cr4.z + pr4.z, cr4.w + pr4.w);
+                *reinterpret_cast<float4*>(wet + (size_t)(tau_0 & (wr - 1))) = ol;
+                *reinterpret_cast<float4*>(wet + (size_t)wr + (tau_0 & (wr - 1))) = orr;
+            }
             wl[0] = ol.x, wl[1] = ol.y, wl[2] = ol.z, wl[3] = ol.w;
             wr_[0] = orr.x, wr_[1] = orr.y, wr_[2] = orr.z, wr_[3] = orr.w;
             if (predelay != 0) {

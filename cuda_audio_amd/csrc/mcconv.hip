@@ -162,6 +162,7 @@ struct mc_engine {
         int slot = 0;
         int first = 0, count = 0;  // output blocks this engine finishes (the whole batch unless block-sliced)
         uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
+        bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
     } pipe[2];
     int pipe_head = 0, pipe_count = 0;
     uint64_t batch_seq = 0;
@@ -175,6 +176,7 @@ struct mc_engine {
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
+    bool inv_to_wet = true;  // whole-batch path: k_inv_wet + ring-reading k_post (MCCONV_INV_WET=0: k_inv + segment ring)
     int slice_first = -1;  // ... and transform only what their windows reach: the slice start must not move
     bool uniform_valid[2] = {false, false};
     BlockParams uniform_bp[2];
@@ -674,8 +676,18 @@ struct MacOut {
     int tail_nsum;
 };
 
-// inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0`
-void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
+// inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0` -
+// or, to_wet, overlap-added straight into the wet ring (only the last block of a launch then stays in the segment ring)
+void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, bool to_wet = false) {
+    auto inv = [&](const float4* y, int64_t sk, int64_t stt, int nsum, int64_t sc, int n, uint64_t b) {
+        const int seg0 = (int)(b & (uint64_t)(e->sr - 1));
+        if (to_wet)
+            hipLaunchKernelGGL(k_inv_wet, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
+                               e->sr, seg0, e->d_wet, e->wr, (int64_t)b * MC_B, e->d_tw);
+        else
+            hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr,
+                               seg0, e->d_tw);
+    };
     if (mo.main_n > 0 && mo.lvl > 0) {
         const int S = 1 << mo.lvl;
         const dim3 cgrid(((mo.main_n + S - 1) / S + 255) / 256, MC_NB);
@@ -685,16 +697,11 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st) {
             hipLaunchKernelGGL(k_ffa_combine<2>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
         else
             hipLaunchKernelGGL(k_ffa_combine<3>, cgrid, dim3(256), 0, st, mo.ysrc, mo.ffa_plane, (int)mo.sk, mo.main_n, e->d_Yc, e->Tcap);
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, e->d_Yc, (int64_t)e->Tcap,
-                           (int64_t)1, 1, (int64_t)0, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
+        inv(e->d_Yc, (int64_t)e->Tcap, (int64_t)1, 1, (int64_t)0, mo.main_n, b0);
     } else if (mo.main_n > 0) {
-        hipLaunchKernelGGL(k_inv, dim3((mo.main_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, mo.ysrc, mo.sk, mo.stt, mo.nsum,
-                           mo.sc, mo.main_n, e->d_seg, e->sr, (int)(b0 & (uint64_t)(e->sr - 1)), e->d_tw);
+        inv(mo.ysrc, mo.sk, mo.stt, mo.nsum, mo.sc, mo.main_n, b0);
     }
-    if (mo.tail_n > 0)
-        hipLaunchKernelGGL(k_inv, dim3((mo.tail_n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, mo.tail_ysrc, mo.tail_sk,
-                           mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, e->d_seg, e->sr,
-                           (int)((b0 + (uint64_t)mo.main_n) & (uint64_t)(e->sr - 1)), e->d_tw);
+    if (mo.tail_n > 0) inv(mo.tail_ysrc, mo.tail_sk, mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, b0 + (uint64_t)mo.main_n);
 }
 
 // Will launch_mac_batch take the second-level transform for this batch?
@@ -1075,6 +1082,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     st.ctx.first = first;
     st.ctx.count = count;
     st.ctx.win0 = wblock * MC_B;
+    // the finished output comes from this engine alone: overlap-add in the inverse-transform kernel, straight into the
+    // wet ring (a partition shard's partial goes through k_ola and the segment ring instead)
+    const bool to_wet = !lin && e->inv_to_wet;
+    st.ctx.wet_ready = to_wet;
     e->pipe[(e->pipe_head + e->pipe_count) % kPipe] = st.ctx;
     e->spec_valid = false;
     BlockParams* d_ptab = st.d_ptab;
@@ -1125,7 +1136,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 HIP_TRY(hipEventRecord(e->ev_mac[par][h], e->stream));
                 HIP_TRY(hipStreamWaitEvent(inv_stream, e->ev_mac[par][h], 0));
             }
-            launch_inv(e, mo, b, inv_stream);
+            launch_inv(e, mo, b, inv_stream, to_wet);
             if (piped && h == 0 && count < e->stream_threshold) {
                 // both parts would use the streaming kernel's partial buffer: the second waits for the first's reader
                 HIP_TRY(hipEventRecord(e->ev_mac[par][0], inv_stream));
@@ -1170,9 +1181,10 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             HIP_TRY(hipStreamWaitEvent(e->post_stream, e->ev_corr[ctx.slot], 0));
             ps = e->post_stream;
         }
-        hipLaunchKernelGGL(k_post, dim3((ctx.count + 3) / 4), dim3(256), 0, ps, e->d_seg, e->sr, lin_sum, e->d_wet, e->wr, e->d_cring,
+        hipLaunchKernelGGL(k_post, dim3((ctx.count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
+                           lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first, ctx.count,
-                           (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
+                           ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
                            make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
                            publish ? ++e->flag_seq : 0u, e->d_done_ctr);
         HIP_TRY(hipGetLastError());
@@ -1656,6 +1668,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
+    if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
