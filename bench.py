@@ -12,10 +12,11 @@ predelay / Q1-Q2 terms / clamp / dry mix, inputs and outputs resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 shards the IR partitions over the ranks (strong scaling): every rank runs
-the forward FFT of the same input, its own share of the MAC and the inverse
-FFT; the partial wet blocks are summed with an RCCL all-reduce and every rank
-finishes (predelay, clamp, dry) on the sum.
+N > 1, default (--shard blocks): every GPU holds the whole IR set and is fed the
+same batch of N x --blocks blocks; rank r finishes output blocks [r, r + 1) x
+--blocks of it - independent units, no data-path collective, weak scaling.
+--shard partitions: IR partitions sharded over the ranks, the partial wet blocks
+summed with an RCCL reduce (the layout that also shortens one real-time period).
 """
 import argparse
 import json
@@ -56,9 +57,11 @@ def parse():
                          "data-path collective, the slices are gathered to rank 0 (default: batch throughput). partitions: "
                          "every GPU holds 1/N of the IR partitions and the partial wet blocks are summed with RCCL (the "
                          "layout that also shortens a single real-time period)")
-    ap.add_argument("--exchange", choices=["gather", "none"], default="gather",
-                    help="--shard blocks: gather the finished slices on rank 0 (default; overlapped with the next batch) or "
-                         "leave every rank's slice where it was computed")
+    ap.add_argument("--exchange", choices=["gather", "none"], default="none",
+                    help="--shard blocks: leave every rank's finished slice on the GPU that computed it (default: like the "
+                         "inputs, the outputs of the batch path live in HBM; at ~150 GB/s of finished audio per GPU any "
+                         "funnel into one GPU is bound by its xGMI links, not by the convolution) or gather the slices "
+                         "on rank 0 over RCCL, overlapped with the next batch")
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
                     help="--shard partitions: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
