@@ -88,7 +88,8 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
                                              float* __restrict__ xhist, int xr,  // [2][xr] input history ring or null
                                              float4* __restrict__ gring, int rc,  // [MC_MAXV][rc] gains of past blocks
                                              int64_t tabs0,                       // absolute block of t = 0
-                                             int need_a0, int need_a1, int need_b0) {
+                                             int need_a0, int need_a1, int need_b0,
+                                             int hist_from) {  // input history is kept from this block on (see run_front)
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
             // whole block of contiguous frames: 16 bytes per lane and access, re-striped through the wave's LDS
             const int64_t f = (int64_t)t * MC_B + 4 * lane;
             const float4 a = *reinterpret_cast<const float4*>(in1 + f), b = *reinterpret_cast<const float4*>(in2 + f);
-            if (xhist) {  // input history for the Q8 pass of later calls
+            if (xhist && t >= hist_from) {  // input history for the Q8 pass of later calls
                 const size_t at = (size_t)((tabs0 * MC_B + f) & (xr - 1));
                 *reinterpret_cast<float4*>(xhist + at) = a;
                 *reinterpret_cast<float4*>(xhist + xr + at) = b;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
             for (int r = 0; r < 4; r++) {  // n = lane + 64 r < 256: the block; 256..511 stay zero
                 int64_t f = (int64_t)t * MC_B + lane + 64 * r;
                 if (f < n_frames) v[r] = make_float2(in1[f * in_stride], in2[f * in_stride]);
-                if (xhist) {  // input history for the Q8 pass of later calls
+                if (xhist && t >= hist_from) {  // input history for the Q8 pass of later calls
                     const int64_t tau = tabs0 * MC_B + f;
                     xhist[(size_t)(tau & (xr - 1))] = v[r].x;
                     xhist[(size_t)xr + (tau & (xr - 1))] = v[r].y;

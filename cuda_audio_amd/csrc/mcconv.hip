@@ -989,7 +989,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
-                           (int64_t)0, 0, Tc, Tc);
+                           (int64_t)0, 0, Tc, Tc, 0);
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
@@ -1094,10 +1094,13 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
 
-    // K1: the blocks this engine can reach (all T unless block-sliced)
+    // K1: the blocks this engine can reach (all T unless block-sliced).  The input history ring serves the Q8 pass of
+    // LATER calls (a batch reads its own samples from its input buffers): they look back less than one reference
+    // length + the largest predelay, so a long batch keeps only its tail.
+    const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
     hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
                        (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
-                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0);
+                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0, hist_from);
     if (e->ktiming && e->kev_n == kEvPool) {
         int rc = drain_kernel_events(e);
         if (rc) return rc;
@@ -1795,7 +1798,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (er == hipSuccess) {
         hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
-                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P);
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0);
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);

@@ -491,6 +491,41 @@ def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack):
     c.close()
 
 
+@pytest.mark.parametrize("sizes", [[120, 120, 60], [150, 1, 1, 148], [70, 230]], ids=["even", "periods_between", "short_then_long"])
+def test_q8_history_across_long_batches(oracle_mod, gpu_lib, sizes):
+    """Q8 with batches longer than the look-back of the pass (one reference length + the largest predelay):
+    k_fwd keeps only the tail of such a batch in the input-history ring; the next call - a batch or single
+    periods - must find everything it looks back to."""
+    from cuda_audio_amd.synth import make_input
+
+    n_ref, taps, pd = 4096, (2500, 3072), 1024
+    nb = sum(sizes)
+    x = make_input(nb * 256)
+    rng = np.random.default_rng(5)
+    irs = []
+    for L in taps:
+        h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (2.0 * L))[:, None]
+        irs.append((h * np.sqrt(0.004 / L)).astype(np.float32))
+    p0, p1 = dict(BASE, predelay=pd), dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=max(sizes))
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    want = ref.process(x[0], x[1])
+    parts, o = [], 0
+    for n in sizes:
+        seg = x[:, o * 256:(o + n) * 256]
+        parts.append(np.stack(c.onProcess(seg[0], seg[1])) if n == 1 else c.process(seg[0], seg[1]))
+        o += n
+    got = np.concatenate(parts, axis=1)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    c.close()
+
+
 @pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
 def test_live_ir_switch_crossfade(oracle_mod, gpu_lib, jack):
     """select CCs while audio runs.  The reference pulls its live spectra towards the newly
