@@ -2301,6 +2301,9 @@ __device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
 }
 
 // forward / inverse transform of the buffer this half of the workgroup (tt = thread within the half, 0..511) owns
+// PAIRS2 = false leaves the radix-2 stage on adjacent pairs to the caller (k_g2_mac applies it to the pair of entries a
+// thread owns while it forms the products, and again before the inverse: two trips through LDS less)
+template <bool PAIRS2 = true>
 __device__ __forceinline__ void g2_forward(float2* s, const float2* t_lo, const float2* t_hi, int tt) {
     g2_pair<false>(s, t_lo, t_hi, tt, tt, 9);  // quarter lengths 2048, 512
     __syncthreads();
@@ -2308,12 +2311,17 @@ __device__ __forceinline__ void g2_forward(float2* s, const float2* t_lo, const 
     __syncthreads();
     g2_pair<false>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);  // 8, 2
     __syncthreads();
-    g2_pairs2(s, tt);
-    __syncthreads();
+    if (PAIRS2) {
+        g2_pairs2(s, tt);
+        __syncthreads();
+    }
 }
+template <bool PAIRS2 = true>
 __device__ __forceinline__ void g2_inverse(float2* s, const float2* t_lo, const float2* t_hi, int tt) {
-    g2_pairs2(s, tt);
-    __syncthreads();
+    if (PAIRS2) {
+        g2_pairs2(s, tt);
+        __syncthreads();
+    }
     g2_pair<true>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);
     __syncthreads();
     g2_pair<true>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31, 5);
@@ -2380,24 +2388,32 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         s[1][G2_P(n)] = make_float2(x.z, x.w);
     }
     __syncthreads();
-    g2_forward(s[half], t_lo, t_hi, tt);
-    // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers
+    g2_forward<false>(s[half], t_lo, t_hi, tt);
+    // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers - the pairs of the
+    // transforms' radix-2 stage, which is applied here on the way in and on the way out
     float2 yl[8], yr[8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int j = threadIdx.x + G2_THREADS * r, idx = 2 * j;
+        int j = threadIdx.x + G2_THREADS * r;
+        asm volatile("" : "+v"(j));  // addresses of this group are formed here, not ahead of the transforms
+        const int idx = 2 * j;
         float2 aL0 = make_float2(0.f, 0.f), aL1 = aL0, aR0 = aL0, aR1 = aL0;
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
             float2 S0, S1;
             if (var) {
-                S0 = s[i][G2_P(g2_mirror(idx))];
-                S1 = s[i][G2_P(g2_mirror(idx + 1))];
+                // -f and -(f + N/2) are a pair again (usually in the other order)
+                const int m0 = g2_mirror(idx), m1 = g2_mirror(idx + 1);
+                const float2 a = s[i][G2_P(m0 & ~1)], b = s[i][G2_P(m0 | 1)];
+                const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
+                S0 = (m0 & 1) ? dif : sum;
+                S1 = (m1 & 1) ? dif : sum;
                 S0.y = -S0.y;
                 S1.y = -S1.y;
             } else {
-                S0 = s[i][G2_P(idx)];
-                S1 = s[i][G2_P(idx + 1)];
+                const float2 a = s[i][G2_P(idx)], b = s[i][G2_P(idx + 1)];
+                S0 = make_float2(a.x + b.x, a.y + b.y);
+                S1 = make_float2(a.x - b.x, a.y - b.y);
             }
             const size_t row = (size_t)(var ? 256 : bin) * G2_N;
 #pragma unroll
@@ -2419,10 +2435,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                 aR1.y = fmaf(gr, pr1.y, aR1.y);
             }
         }
-        yl[2 * r] = aL0;
-        yl[2 * r + 1] = aL1;
-        yr[2 * r] = aR0;
-        yr[2 * r + 1] = aR1;
+        yl[2 * r] = make_float2(aL0.x + aL1.x, aL0.y + aL1.y);
+        yl[2 * r + 1] = make_float2(aL0.x - aL1.x, aL0.y - aL1.y);
+        yr[2 * r] = make_float2(aR0.x + aR1.x, aR0.y + aR1.y);
+        yr[2 * r + 1] = make_float2(aR0.x - aR1.x, aR0.y - aR1.y);
         asm volatile("" ::: "memory");  // one group of loads in flight at a time: keeps the kernel free of spills
     }
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
@@ -2435,7 +2451,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         s[1][G2_P(idx + 1)] = yr[2 * r + 1];
     }
     __syncthreads();
-    g2_inverse(s[half], t_lo, t_hi, tt);
+    g2_inverse<false>(s[half], t_lo, t_hi, tt);
     const float sc = 1.0f / (float)G2_N;
     float4* dst = Yc + (size_t)bin * ycap + t_c0;
     for (int t = threadIdx.x; t < nout; t += G2_THREADS) {
