@@ -1105,6 +1105,8 @@ __device__ __forceinline__ float2 wet_at(const float* __restrict__ seg, int sr, 
     return make_float2(0.f, 0.f);
 }
 
+// TD = false: the variant for calls whose Q8 pass is off (no tail_drop code, half the registers)
+template <bool TD>
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
                                               float* wet, int wr, const double* __restrict__ cring, int rc,
                                               const BlockParams* __restrict__ ptab, int pstride,
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                 }
             }
             float a = wl[k], b = wr_[k];
-            if (td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
+            if (TD && td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
                 float dl, dr;
                 tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
                 a -= dl;

@@ -1184,11 +1184,12 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             HIP_TRY(hipStreamWaitEvent(e->post_stream, e->ev_corr[ctx.slot], 0));
             ps = e->post_stream;
         }
-        hipLaunchKernelGGL(k_post, dim3((ctx.count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
+        const TailDrop td = make_taildrop(e, ctx.vir, ctx.predelay);
+        hipLaunchKernelGGL(td.on ? k_post<true> : k_post<false>, dim3((ctx.count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first, ctx.count,
                            ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
-                           make_taildrop(e, ctx.vir, ctx.predelay), e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
+                           td, e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
                            publish ? ++e->flag_seq : 0u, e->d_done_ctr);
         HIP_TRY(hipGetLastError());
         if (piped) {
