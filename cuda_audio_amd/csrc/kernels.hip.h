@@ -93,27 +93,29 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
-    __shared__ float2 s_fft[XF_WAVES][FFT_WAVE_LDS];
-    __shared__ float4 s_tile[MC_NB][FWD_TILE + 1];
+    // eight wave-private transform buffers, then (every wave has its spectra in registers) the transposed tile
+    // [256 bins][8 blocks + 1] of float4 in the same memory: 41 KB of LDS, three workgroups per CU
+    __shared__ __align__(16) float2 s_mem[XF_WAVES * FFT_WAVE_LDS];
+    static_assert(XF_WAVES == FWD_TILE, "one wave per block of the tile");
+    static_assert(sizeof(float2) * XF_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (FWD_TILE + 1), "tile fits the transform buffers");
+    float4(*s_tile)[FWD_TILE + 1] = reinterpret_cast<float4(*)[FWD_TILE + 1]>(s_mem);
     load_twiddles(s_tw, g_tw);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb0 = blockIdx.x * FWD_TILE;
-    float2* lds = s_fft[wave];
+    float2* lds = s_mem + wave * FFT_WAVE_LDS;
     auto needed = [&](int t) { return (t >= need_a0 && t < need_a1) || t >= need_b0; };
     const bool vec_in = in_stride == 1 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
-    for (int it = 0; it < FWD_TILE / XF_WAVES; it++) {
-        const int tb = it * XF_WAVES + wave;  // block within tile
-        const int t = tb0 + tb;
-        if (t < T && !needed(t)) {  // wave-uniform
-            if (sums && lane == 0) sums[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();  // the one workgroup barrier of an iteration
-            continue;
-        }
+    const int tb = wave;  // block within tile
+    const int t = tb0 + tb;
+    const bool active = t < T && needed(t);  // wave-uniform
+    if (t < T && !active && sums && lane == 0) sums[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xs[4];
+    if (active) {
         float2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = make_float2(0.f, 0.f);
-        if (t < T && vec_in && (int64_t)(t + 1) * MC_B <= n_frames) {
+        if (vec_in && (int64_t)(t + 1) * MC_B <= n_frames) {
             // whole block of contiguous frames: 16 bytes per lane and access, re-striped through the wave's LDS
             const int64_t f = (int64_t)t * MC_B + 4 * lane;
             const float4 a = *reinterpret_cast<const float4*>(in1 + f), b = *reinterpret_cast<const float4*>(in2 + f);
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = lds[lane + 64 * r];
             fft_sync<false>();
-        } else if (t < T) {
+        } else {
 #pragma unroll
             for (int r = 0; r < 4; r++) {  // n = lane + 64 r < 256: the block; 256..511 stay zero
                 int64_t f = (int64_t)t * MC_B + lane + 64 * r;
@@ -143,32 +145,34 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
             }
         }
         fft512_wave<-1, false>(v, lds, s_tw, lane);  // wave-private LDS: waves that skip a block stay out of it
-        if (t < T) {
-            // two-for-one split of the packed transform (true spectra; the
-            // reference's DC/Nyquist shortcuts Q1/Q2 are rank-1 terms added in k_post)
+        // two-for-one split of the packed transform (true spectra; the
+        // reference's DC/Nyquist shortcuts Q1/Q2 are rank-1 terms added in k_post)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int k = lane + 64 * j;
-                float2 za = lds[k], zb = lds[(FFT_N - k) & (FFT_N - 1)];
-                float2 x1, x2;
-                if (k == 0) {
-                    float2 zn = lds[MC_B];
-                    x1 = make_float2(za.x, zn.x);  // {DC, Nyquist} of input 1
-                    x2 = make_float2(za.y, zn.y);  // {DC, Nyquist} of input 2
-                    if (sums) sums[t] = make_float4(za.x, za.y, zn.x, zn.y);  // S1, S2, A1, A2
-                } else {
-                    x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
-                    x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
-                }
-                s_tile[k][tb] = make_float4(x1.x, x1.y, x2.x, x2.y);
+        for (int j = 0; j < 4; j++) {
+            int k = lane + 64 * j;
+            float2 za = lds[k], zb = lds[(FFT_N - k) & (FFT_N - 1)];
+            float2 x1, x2;
+            if (k == 0) {
+                float2 zn = lds[MC_B];
+                x1 = make_float2(za.x, zn.x);  // {DC, Nyquist} of input 1
+                x2 = make_float2(za.y, zn.y);  // {DC, Nyquist} of input 2
+                if (sums) sums[t] = make_float4(za.x, za.y, zn.x, zn.y);  // S1, S2, A1, A2
+            } else {
+                x1 = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y));
+                x2 = make_float2(0.5f * (za.y + zb.y), -0.5f * (za.x - zb.x));
             }
-            if (slotgain && lane < MC_MAXV) {
-                const float* gv = ptab[(int64_t)t * pstride].g[lane];
-                slotgain[(size_t)lane * ring + ((slot0 + t) & (ring - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
-                if (gring) gring[(size_t)lane * rc + (size_t)((tabs0 + t) & (rc - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
-            }
+            xs[j] = make_float4(x1.x, x1.y, x2.x, x2.y);
         }
-        __syncthreads();  // lds reused by the next transform
+        if (slotgain && lane < MC_MAXV) {
+            const float* gv = ptab[(int64_t)t * pstride].g[lane];
+            slotgain[(size_t)lane * ring + ((slot0 + t) & (ring - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            if (gring) gring[(size_t)lane * rc + (size_t)((tabs0 + t) & (rc - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+    }
+    __syncthreads();  // every wave has read its transform: the buffers become the tile
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) s_tile[lane + 64 * j][tb] = xs[j];
     }
     __syncthreads();
     // transposed, coalesced store: 8 consecutive slots (128 B) per bin
