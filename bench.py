@@ -38,8 +38,8 @@ FP32_PEAK_TFLOPS = 157.3  # vector = f32-MFMA rate
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=19392,
                     help="blocks per step (batch length T). 19392 = 112.6 s of audio = three full chunks of the second-level "
                          "transform for the 1723-partition IR (chunk = 8192 - 1728 + 1 blocks), one halo block to spare")
