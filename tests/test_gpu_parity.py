@@ -1363,7 +1363,8 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
     than a chunk."""
     from cuda_audio_amd.synth import make_input, make_ir
 
-    sizes = [3, 1200, 4098, 15000 if n_ref == 131072 else 4096]
+    # (the last one: bench.py's step for the 10 s IR, three full chunks of the fused form)
+    sizes = [3, 1200, 4098, 15000 if n_ref == 131072 else 19392]
     if n_ref == 131072:
         sizes += [4096, 4096]  # a gain change before the first of these: its window carries two sets of gains
     nb = sum(sizes)
