@@ -99,17 +99,22 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
     static_assert(XF_WAVES == FWD_TILE, "one wave per block of the tile");
     static_assert(sizeof(float2) * XF_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (FWD_TILE + 1), "tile fits the transform buffers");
     float4(*s_tile)[FWD_TILE + 1] = reinterpret_cast<float4(*)[FWD_TILE + 1]>(s_mem);
-    load_twiddles(s_tw, g_tw);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb0 = blockIdx.x * FWD_TILE;
-    float2* lds = s_mem + wave * FFT_WAVE_LDS;
     auto needed = [&](int t) { return (t >= need_a0 && t < need_a1) || t >= need_b0; };
-    const bool vec_in = in_stride == 1 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
     const int tb = wave;  // block within tile
     const int t = tb0 + tb;
     const bool active = t < T && needed(t);  // wave-uniform
     if (t < T && !active && sums && lane == 0) sums[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        // a tile none of whose blocks is needed (most tiles of a block-sliced rank) ends here, before any barrier
+        const int lo = tb0, hi = min(tb0 + FWD_TILE, T);  // [lo, hi) against [need_a0, need_a1) and [need_b0, T)
+        if (!((lo < need_a1 && hi > need_a0) || hi > need_b0)) return;
+    }
+    load_twiddles(s_tw, g_tw);
+    __syncthreads();
+    float2* lds = s_mem + wave * FFT_WAVE_LDS;
+    const bool vec_in = in_stride == 1 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
     float4 xs[4];
     if (active) {
         float2 v[8];
