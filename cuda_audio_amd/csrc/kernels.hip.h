@@ -750,26 +750,27 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
 // ---------------------------------------------------------------------------
 // K3w: inverse transform + overlap-add straight into the wet ring (whole-batch
 // path; k_post then reads the ring instead of the segment ring, which saves the
-// 4 KB per block round trip through memory).  A workgroup finishes the 8 blocks
-// of its tile; a ninth wave repeats the inverse of the block before the tile
-// (its second half is the other addend of the tile's first block) - for the
-// first tile of a launch that half comes from the segment ring, where the last
-// block of every launch is kept in full for the next launch / call.
-// The transforms reuse the memory of the transposed tile (all nine waves have
-// their inputs in registers by then): 45.5 KB of LDS, three workgroups per CU.
-// Y element as in k_inv.  wet[ch][(tau0 + 256 t + m) mod wr].  grid = ceil(T/8), block = 576.
+// 4 KB per block round trip through memory).  A workgroup finishes the 15
+// blocks of its tile; a sixteenth wave repeats the inverse of the block before
+// the tile (its second half is the other addend of the tile's first block) -
+// for the first tile of a launch that half comes from the segment ring, where
+// the last block of every launch is kept in full for the next launch / call.
+// The transforms reuse the memory of the transposed tile (all waves have their
+// inputs in registers by then): 78 KB of LDS, two workgroups = 32 waves per CU.
+// Y element as in k_inv.  wet[ch][(tau0 + 256 t + m) mod wr].  grid = ceil(T/15), block = 1024.
 // ---------------------------------------------------------------------------
-#define IW_WAVES (FWD_TILE + 1)
+#define IW_WAVES 16            // 15 blocks of the tile + the block before it: a multiple of the four SIMDs, two workgroups
+#define IW_NEW (IW_WAVES - 1)  // fill a CU's 32 wave slots (nine-wave workgroups put three waves on one SIMD: only two fit)
 #define IW_THREADS (64 * IW_WAVES)
 __global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                                         int T, float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet,
                                                         int wr, int64_t tau0, const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
-    __shared__ __align__(16) float2 s_mem[IW_WAVES * FFT_WAVE_LDS];  // tile [256 bins][9 blocks] of float4, then 9 transforms
-    static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * IW_WAVES, "tile fits the transform buffers");
-    float4(*s_tile)[IW_WAVES] = reinterpret_cast<float4(*)[IW_WAVES]>(s_mem);
+    __shared__ __align__(16) float2 s_mem[IW_WAVES * FFT_WAVE_LDS];  // tile [256 bins][16 blocks + 1] of float4, then 16 transforms
+    static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (IW_WAVES + 1), "tile fits the transform buffers");
+    float4(*s_tile)[IW_WAVES + 1] = reinterpret_cast<float4(*)[IW_WAVES + 1]>(s_mem);
     load_twiddles(s_tw, g_tw);
-    const int tb0 = blockIdx.x * FWD_TILE;
+    const int tb0 = blockIdx.x * IW_NEW;
     {
         const int c = threadIdx.x % IW_WAVES, k0 = threadIdx.x / IW_WAVES;  // column c <-> block tb0 - 1 + c
         const int t = tb0 - 1 + c;

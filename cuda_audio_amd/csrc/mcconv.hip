@@ -682,7 +682,7 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, boo
     auto inv = [&](const float4* y, int64_t sk, int64_t stt, int nsum, int64_t sc, int n, uint64_t b) {
         const int seg0 = (int)(b & (uint64_t)(e->sr - 1));
         if (to_wet)
-            hipLaunchKernelGGL(k_inv_wet, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
+            hipLaunchKernelGGL(k_inv_wet, dim3((n + IW_NEW - 1) / IW_NEW), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
                                e->sr, seg0, e->d_wet, e->wr, (int64_t)b * MC_B, e->d_tw);
         else
             hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr,
