@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], the one the metric is quoted on): stereo
 44.1 kHz, 256-frame blocks, 10 s / 441 000-tap IR (P = 1723 partitions,
 N_ref = 524288), reference routing (2 inputs x 2 outputs = 4 convolution
-paths), fp32.  One "step" = one batch of --blocks (default 19392) consecutive blocks pushed
+paths), fp32.  One "step" = one batch of --blocks (default 32320) consecutive blocks pushed
 through forward FFT -> partition x bin MAC -> inverse FFT -> overlap-add ->
 predelay / Q1-Q2 terms / clamp / dry mix, inputs and outputs resident in HBM.
 
@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=19392,
-                    help="blocks per step (batch length T). 19392 = 112.6 s of audio = three full chunks of the second-level "
-                         "transform for the 1723-partition IR (chunk = 8192 - 1728 + 1 blocks), one halo block to spare")
+    ap.add_argument("--blocks", type=int, default=32320,
+                    help="blocks per step (batch length T). 32320 = 187.6 s of audio = five full chunks of the second-level "
+                         "transform for the 1723-partition IR (chunk = 8192 - 1728 + 1 blocks), one halo block to spare; the "
+                         "longest such batch for which 8 block-sliced ranks stay within mc_config.max_batch (262144)")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
