@@ -2115,11 +2115,14 @@ struct Fft2Voices {
 // together, and the second reader finds the data in that XCD's L2.
 // Sequences per (bin, chunk): uniform gains - the 2 inputs (gains applied in the product); per-slot gains - for
 // every voice v and path (c, i) the sequence gain_v,c,i(slot) * X_i(slot): nseq = 4 * voices, index v * 4 + c * 2 + i.
+// The chunks of a group of 8 bins follow each other, so that on every XCD the chunks of ITS bin of the group run
+// together: the IR's second-level spectra of the bin and the overlap of adjacent windows are read once into that L2.
 __device__ __forceinline__ void f2_decode(int id, int nz, int& bin, int& chunk, int& z) {
+    const int nch = (int)gridDim.x / (MC_NB * nz);
     const int g = id / (8 * nz), w = id - g * 8 * nz;  // nz workgroups per (bin, chunk), 8 bins per group
     z = w >> 3;
-    bin = ((g & 31) << 3) + (w & 7);
-    chunk = g >> 5;
+    bin = ((g / nch) << 3) + (w & 7);
+    chunk = g % nch;
 }
 struct Fft2Gains {
     const float4* row[MC_MAXV];  // per-slot gain table of each voice (null: uniform gains, nseq = 2)
@@ -2384,7 +2387,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                                                        int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap) {
     __shared__ float2 s[2][G2_LDS];
     __shared__ float2 t_lo[128], t_hi[64];
-    const int bin = blockIdx.x & (MC_NB - 1), chunk = blockIdx.x >> 8;
+    // block ids 8 apart run on one XCD: there the chunks of a bin follow each other, so that the bin's second-level
+    // spectra (262 KB for four paths) and the overlap of adjacent windows are read once into that XCD's L2
+    const int nch = gridDim.x >> 8, xq = blockIdx.x >> 3;
+    const int bin = (xq / nch) * 8 + (blockIdx.x & 7), chunk = xq % nch;
     const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
     const float4* fk = fdl + (size_t)bin * ring;
     const int sb = slot0 + t_c0 - (taps - 1);
