@@ -501,7 +501,9 @@ def main():
                             "inputs' spectra side by side in 133 KB of LDS, k_g2_mac; 16384 points through a stash for long IRs "
                             "and per-slot gains, k_f2_fwd + k_f2_prod) against the IRs' transformed partition sequences. "
                             "achieved = the kernel's own algorithmic bytes (delay-line window, second-level spectra of 4 paths "
-                            "per chunk, partition sums written; the split form also its stash) / kernel time (HIP events on the launch stream); `replaces` prices the same launch as "
+                            "per chunk, partition sums written; the split form also its stash) / kernel time (HIP events on the launch stream); `traffic` "
+                            "(HBM side, PMC counters) is lower because the chunks of a bin run together on one XCD and share its spectra and "
+                            "the overlap of their windows in that L2; `replaces` prices the same launch as "
                             "the direct-form MAC it stands for (SURVEY 8(d) accounting). MCCONV_FFT2=0 runs the MAC kernel "
                             "(fast-FIR form), MCCONV_FFA_LEVELS=0 its direct form.")
     elif ks["resident"]:
