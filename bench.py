@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[2], the one the metric is quoted on): stereo
 44.1 kHz, 256-frame blocks, 10 s / 441 000-tap IR (P = 1723 partitions,
 N_ref = 524288), reference routing (2 inputs x 2 outputs = 4 convolution
-paths), fp32.  One "step" = one batch of --blocks (default 32320) consecutive blocks pushed
+paths), fp32.  One "step" = one batch of --blocks (default: the engine's preferred length, 32320) consecutive blocks pushed
 through forward FFT -> partition x bin MAC -> inverse FFT -> overlap-add ->
 predelay / Q1-Q2 terms / clamp / dry mix, inputs and outputs resident in HBM.
 
@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--blocks", type=int, default=32320,
-                    help="blocks per step (batch length T). 32320 = 187.6 s of audio = five full chunks of the second-level "
-                         "transform for the 1723-partition IR (chunk = 8192 - 1728 + 1 blocks), one halo block to spare; the "
-                         "longest such batch for which 8 block-sliced ranks stay within mc_config.max_batch (262144)")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="blocks per step (batch length T). 0 (default): what the engine prefers up to 32768 blocks "
+                         "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 32320 = 187.6 s "
+                         "of audio = five chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR; 8 block-sliced ranks "
+                         "then stay within mc_config.max_batch (262144)")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
@@ -168,8 +169,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    T = a.blocks
     ir = make_ir(a.taps, seed=5678)
+    if a.blocks <= 0:
+        probe = Convolution("probe", a.fft_size, max_batch=32768, device=local)
+        probe.prepare(0, ir)
+        a.blocks = probe.preferred_batch(32768)
+        probe.close()
+    T = a.blocks
     P = (min(a.taps, a.fft_size - 1024) + BLOCK - 1) // BLOCK
     # shard bounds: multiples of 16 partitions
     from cuda_audio_amd.sharded import shard_bounds

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mc_reset", "mc_set_period", "mc_load_ir", "mc_num_irs", "mc_ir_info", "mc_set_params", "mc_get_params", "mc_handle_cc",
     "mc_process", "mc_process_batch", "mc_process_batch_device", "mc_partial_batch_device",
     "mc_finish_batch_device", "mc_process_batch_slice_device", "mc_sync", "mc_fence", "mc_fence_older", "mc_set_stream", "mc_get_stream", "mc_avg_runtime_ms",
-    "mc_enable_kernel_timing", "mc_get_kernel_stats", "mc_algorithmic_bytes_per_block", "mc_blocks_processed",
+    "mc_enable_kernel_timing", "mc_get_kernel_stats", "mc_algorithmic_bytes_per_block", "mc_blocks_processed", "mc_preferred_batch",
     "mc_debug_read",
 ]
 
@@ -133,6 +133,8 @@ def load():
     L.mc_algorithmic_bytes_per_block.restype = u64
     L.mc_blocks_processed.argtypes = [vp]
     L.mc_blocks_processed.restype = u64
+    L.mc_preferred_batch.argtypes = [vp, u64]
+    L.mc_preferred_batch.restype = u64
     L.mc_debug_read.argtypes = [vp, C.c_int, u64, vp, u64, u64, C.POINTER(u64)]
     _lib = L
     return L

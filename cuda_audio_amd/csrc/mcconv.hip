@@ -2046,6 +2046,23 @@ uint64_t mc_algorithmic_bytes_per_block(const mc_engine* e) {
 
 uint64_t mc_blocks_processed(const mc_engine* e) { return e ? e->t_abs : 0; }
 
+uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
+    if (!e) return 0;
+    mc_engine* m = const_cast<mc_engine*>(e);
+    std::lock_guard<std::mutex> lk(m->pmu);
+    at_most = std::min<uint64_t>(at_most, (uint64_t)e->Tmax);
+    int pmax = 0;
+    for (int i = 0; i < kMaxIrs; i++)
+        if (e->irs[i].d_H) pmax = std::max(pmax, round_up(e->irs[i].P, 16));
+    uint64_t chunk = 0;
+    if (e->fft2 && !e->half && !e->cfg.part_begin && !e->cfg.part_end && pmax >= 256) {
+        if (e->fft2_fused && pmax <= 2560) chunk = (uint64_t)(G2_N - pmax + 1);
+        else if (pmax <= F2_N / 2) chunk = (uint64_t)(F2_N - pmax + 1);
+    }
+    if (!chunk || at_most < chunk) return at_most >= 8 ? (at_most & ~(uint64_t)7) : at_most;
+    return ((at_most + 1) / chunk * chunk - 1) & ~(uint64_t)7;
+}
+
 int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off, uint64_t bytes, uint64_t dims[4]) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));

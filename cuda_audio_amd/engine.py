@@ -227,6 +227,11 @@ class Convolution:
     def algorithmic_bytes_per_block(self):
         return self._L.mc_algorithmic_bytes_per_block(self._h)
 
+    def preferred_batch(self, at_most):
+        """Batch length (blocks) <= at_most that wastes nothing of the second-level transform's chunks for the
+        loaded IRs (mc_preferred_batch)."""
+        return int(self._L.mc_preferred_batch(self._h, int(at_most)))
+
     def blocks_processed(self):
         return self._L.mc_blocks_processed(self._h)
 

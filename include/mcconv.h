@@ -181,6 +181,12 @@ int mc_enable_kernel_timing(mc_engine *e, int on); /* HIP events around the MAC 
 int mc_get_kernel_stats(mc_engine *e, mc_kernel_stats *out, int reset);
 uint64_t mc_algorithmic_bytes_per_block(const mc_engine *e); /* (4 paths + 2 inputs) * P * 2048 */
 uint64_t mc_blocks_processed(const mc_engine *e);
+/* Batch length (blocks, a multiple of 8, <= at_most and <= max_batch) that suits the loaded IRs best: long batches
+ * take the sum over partitions as a second-level transform in chunks of 8192 - P16 + 1 blocks (16384 - P16 + 1 for
+ * IRs over 2560 partitions; P16 = partitions of the longest loaded IR rounded up to 16), so whole chunks - minus one
+ * block, the reach-back of a block slice - waste nothing.  at_most shorter than a chunk is returned as it is
+ * (rounded down to 8).  No reference equivalent (batch calls are new). */
+uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
 
 /* Diagnostics (tests only): copy `bytes` from an engine-owned device buffer to host.
  * which: 0 = IR spectra of IR `idx` (float4 [256][pstride]), 1 = delay line

@@ -1352,6 +1352,26 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
     assert np.array_equal(outs[0], outs[1]), f"rms difference {rms(outs[0] - outs[1]):.3e}"
 
 
+def test_preferred_batch_length(gpu_lib):
+    """mc_preferred_batch: whole chunks of the second-level transform for the longest loaded IR, minus one block,
+    a multiple of 8, within at_most and max_batch; short limits come back as they are."""
+    from cuda_audio_amd.synth import make_ir
+
+    c = _conv(fftSize=524288, max_batch=40000)
+    assert c.preferred_batch(1000) == 1000  # nothing loaded: no preference
+    c.prepare(0, make_ir(441000, seed=1))   # 1723 partitions -> 1728: chunks of 8192 - 1728 + 1 = 6465 blocks
+    assert c.preferred_batch(32768) == 32320
+    assert c.preferred_batch(20000) == 19392
+    assert c.preferred_batch(6465) == 6464
+    assert c.preferred_batch(6000) == 6000
+    assert c.preferred_batch(10 ** 9) == (6 * 6465 - 1) // 8 * 8  # capped by max_batch = 40000
+    c.close()
+    c = _conv(fftSize=2097152, max_batch=40000)
+    c.prepare(0, make_ir(1323000, seed=2))  # 5168 partitions: the 16384-point form, chunks of 11217
+    assert c.preferred_batch(32768) == (2 * 11217 - 1) // 8 * 8
+    c.close()
+
+
 @pytest.mark.parametrize("fused", [False, True], ids=["split", "fused"])
 @pytest.mark.parametrize("n_ref,taps", [(131072, (88200, 80000)), (524288, (441000, 400000))], ids=["P345", "P1723"])
 def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, fused):
