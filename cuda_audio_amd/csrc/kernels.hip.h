@@ -89,7 +89,8 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
                                              float4* __restrict__ gring, int rc,  // [MC_MAXV][rc] gains of past blocks
                                              int64_t tabs0,                       // absolute block of t = 0
                                              int need_a0, int need_a1, int need_b0,
-                                             int hist_from) {  // input history is kept from this block on (see run_front)
+                                             int hist_from,  // input history is kept from this block on (see run_front)
+                                             int t_base) {   // first block of this launch (a block-sliced rank launches its ranges)
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
     static_assert(sizeof(float2) * XF_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (FWD_TILE + 1), "tile fits the transform buffers");
     float4(*s_tile)[FWD_TILE + 1] = reinterpret_cast<float4(*)[FWD_TILE + 1]>(s_mem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tb0 = blockIdx.x * FWD_TILE;
+    const int tb0 = t_base + blockIdx.x * FWD_TILE;
     auto needed = [&](int t) { return (t >= need_a0 && t < need_a1) || t >= need_b0; };
     const int tb = wave;  // block within tile
     const int t = tb0 + tb;
@@ -953,13 +954,14 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
 __global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
                                                            int pstride, int T, VoiceSums vs, double inv_n, int compat,
                                                            double* __restrict__ cring, int rc, int64_t tabs0,
-                                                           double* __restrict__ ctot) {
+                                                           double* __restrict__ ctot, int need_a0, int need_a1, int need_b0) {
+    // blocks outside [need_a0, need_a1) and [need_b0, T) were not transformed (block-sliced rank): zero terms
     // T <= CORR_CHUNK (one workgroup): the base of the previous batch is added here and k_corr_fix is not run
     __shared__ double s_part[CORR_CHUNK][4];
     const int tid = threadIdx.x;
     const int t = blockIdx.x * CORR_CHUNK + tid;
     double d[4] = {0, 0, 0, 0};
-    if (t < T && compat) corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
+    if (t < T && compat && ((t >= need_a0 && t < need_a1) || t >= need_b0)) corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
     if (T <= CORR_CHUNK && tid == 0 && tabs0 > 0) {
         const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) d[c] += p[c];

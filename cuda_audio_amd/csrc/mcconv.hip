@@ -161,6 +161,7 @@ struct mc_engine {
         int vir[2][MC_MAXV];  // IR index per half and voice (-1 = none)
         int slot = 0;
         int first = 0, count = 0;  // output blocks this engine finishes (the whole batch unless block-sliced)
+        int need_a0 = 0, need_a1 = 0, need_b0 = 0;  // blocks the front half transformed: [a0, a1) and [b0, T)
         uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
         bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
     } pipe[2];
@@ -989,7 +990,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
-                           (int64_t)0, 0, Tc, Tc, 0);
+                           (int64_t)0, 0, Tc, Tc, 0, 0);
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
@@ -1081,6 +1082,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     const uint64_t wblock = e->t_front + (uint64_t)first - (uint64_t)halo;  // first block of the window (absolute)
     st.ctx.first = first;
     st.ctx.count = count;
+    st.ctx.need_a0 = need_a0;
+    st.ctx.need_a1 = need_a1;
+    st.ctx.need_b0 = need_b0;
     st.ctx.win0 = wblock * MC_B;
     // the finished output comes from this engine alone: overlap-add in the inverse-transform kernel, straight into the
     // wet ring (a partition shard's partial goes through k_ola and the segment ring instead)
@@ -1098,9 +1102,17 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // LATER calls (a batch reads its own samples from its input buffers): they look back less than one reference
     // length + the largest predelay, so a long batch keeps only its tail.
     const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
-    hipLaunchKernelGGL(k_fwd, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
-                       (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw, e->d_fdl16,
-                       e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0, hist_from);
+    {
+        // one launch per run of needed blocks (a whole-batch call: one launch over everything)
+        int lo[2] = {need_a0 & ~(FWD_TILE - 1), need_b0 & ~(FWD_TILE - 1)}, hi[2] = {need_a1, T};
+        if (lo[1] <= hi[0]) hi[0] = T, lo[1] = T;  // the two runs meet
+        for (int r = 0; r < 2; r++)
+            if (hi[r] > lo[r])
+                hipLaunchKernelGGL(k_fwd, dim3((hi[r] - lo[r] + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
+                                   (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw,
+                                   e->d_fdl16, e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0,
+                                   hist_from, lo[r]);
+    }
     if (e->ktiming && e->kev_n == kEvPool) {
         int rc = drain_kernel_events(e);
         if (rc) return rc;
@@ -1173,7 +1185,8 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
         const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
         hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
-                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot);
+                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot, ctx.need_a0,
+                           ctx.need_a1, ctx.need_b0);
         if (nchunks > 1)  // a single chunk adds its base itself
             hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
                                e->d_ctot);
@@ -1799,7 +1812,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (er == hipSuccess) {
         hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
-                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0);
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0, 0);
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
