@@ -1928,6 +1928,57 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
 #define F2_THREADS 1024
 
 __device__ __forceinline__ float2 f2_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// The transforms' arithmetic on two-element vectors, the complex products and the +-j rotations spelled out as the
+// packed instructions they are (operand swizzles and sign modifiers of v_pk_mul / v_pk_fma / v_pk_add): 144 VALU
+// instructions per radix-16 pass and thread.  From the same arithmetic on float2 structs the compiler re-packs scalar
+// operations through 70 register moves (262 instructions); from plain vector expressions it still materialises the
+// lane-wise negations (186).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vx_ld(const float2* p) { return *reinterpret_cast<const v2f*>(p); }
+__device__ __forceinline__ void vx_st(float2* p, v2f v) { *reinterpret_cast<v2f*>(p) = v; }
+// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ v2f vx_mul(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ v2f vx_mulc(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a - j b = (a.x + b.y, a.y - b.x) and a + j b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f vx_sub_j(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f vx_add_j(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// radix-4 butterfly in place: forward y_m = sum_n a_n (-j)^(mn), inverse with +j
+template <bool INV>
+__device__ __forceinline__ void vx_bfly4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = INV ? vx_add_j(t1, t3) : vx_sub_j(t1, t3);
+    a3 = INV ? vx_sub_j(t1, t3) : vx_add_j(t1, t3);
+}
+// a1, a2, a3 *= w, w^2, w^3 (INV: their conjugates)
+template <bool INV>
+__device__ __forceinline__ void vx_tw3(v2f& a1, v2f& a2, v2f& a3, v2f w) {
+    const v2f w2 = vx_mul(w, w), w3 = vx_mul(w2, w);
+    a1 = INV ? vx_mulc(a1, w) : vx_mul(a1, w);
+    a2 = INV ? vx_mulc(a2, w2) : vx_mul(a2, w2);
+    a3 = INV ? vx_mulc(a3, w3) : vx_mul(a3, w3);
+}
+__device__ __forceinline__ v2f vx_tw(const float2* t_lo, const float2* t_hi, int e) { return vx_mul(vx_ld(t_lo + (e & 127)), vx_ld(t_hi + (e >> 7))); }
 __device__ __forceinline__ float2 f2_mulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
@@ -1984,36 +2035,36 @@ template <bool INV>
 __device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
     const int Q = 1 << lq;
     const int step1 = F2_N >> (lq + 4), step2 = F2_N >> (lq + 2);
-    float2 a[16];
+    v2f a[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = s[F2_P(pos0 + Q * m)];
+    for (int m = 0; m < 16; m++) a[m] = vx_ld(&s[F2_P(pos0 + Q * m)]);
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            f2_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
-            f2_tw3<false>(a[r + 4], a[r + 8], a[r + 12], f2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], vx_tw(t_lo, t_hi, (j0 + Q * r) * step1));
         }
-        const float2 w = f2_tw(t_lo, t_hi, j0 * step2);
+        const v2f w = vx_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            f2_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-            f2_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            vx_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            vx_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
         }
     } else {
-        const float2 w = f2_tw(t_lo, t_hi, j0 * step2);
+        const v2f w = vx_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            f2_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
-            f2_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            vx_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            vx_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            f2_tw3<true>(a[r + 4], a[r + 8], a[r + 12], f2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
-            f2_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], vx_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < 16; m++) s[F2_P(pos0 + Q * m)] = a[m];
+    for (int m = 0; m < 16; m++) vx_st(&s[F2_P(pos0 + Q * m)], a[m]);
 }
 
 // the last forward / first inverse stage (quarter length 1, no twiddles): four butterflies per thread on quads of
@@ -2021,17 +2072,17 @@ __device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const flo
 template <bool INV>
 __device__ __forceinline__ void f2_quads(float2* s, int t) {
     const int G = t & 255, u0 = t >> 8;
-    float2 a[16];
+    v2f a[16];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) a[4 * r + k] = s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)];
+        for (int k = 0; k < 4; k++) a[4 * r + k] = vx_ld(&s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)]);
 #pragma unroll
-    for (int r = 0; r < 4; r++) f2_bfly4<INV>(a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]);
+    for (int r = 0; r < 4; r++) vx_bfly4<INV>(a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]);
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)] = a[4 * r + k];
+        for (int k = 0; k < 4; k++) vx_st(&s[F2_P(64 * G + 4 * (u0 + 4 * r) + k)], a[4 * r + k]);
 }
 
 // natural order in, digit-reversed order out (unscaled forward transform); every pass moves the sequence through
@@ -2254,6 +2305,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #define G2_THREADS 1024
 
 __device__ __forceinline__ float2 g2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
+__device__ __forceinline__ v2f vg_tw(const float2* t_lo, const float2* t_hi, int e) { return vx_mul(vx_ld(t_lo + (e & 127)), vx_ld(t_hi + (e >> 7))); }
 
 __device__ __forceinline__ void g2_tables(float2* t_lo, float2* t_hi) {  // w = exp(-2 pi i / 8192): w^k (128), w^(128 k) (64)
     if (threadIdx.x < 192) {
@@ -2273,36 +2325,36 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
     // LDS addresses are recomputed in every pass: shared between the forward and the inverse transform they would stay
     // live across the whole kernel and spill
     asm volatile("" : "+v"(pos0), "+v"(j0));
-    float2 a[16];
+    v2f a[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = s[G2_P(pos0 + Q * m)];
+    for (int m = 0; m < 16; m++) a[m] = vx_ld(&s[G2_P(pos0 + Q * m)]);
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            f2_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
-            f2_tw3<false>(a[r + 4], a[r + 8], a[r + 12], g2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], vg_tw(t_lo, t_hi, (j0 + Q * r) * step1));
         }
-        const float2 w = g2_tw(t_lo, t_hi, j0 * step2);
+        const v2f w = vg_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            f2_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-            f2_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            vx_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            vx_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
         }
     } else {
-        const float2 w = g2_tw(t_lo, t_hi, j0 * step2);
+        const v2f w = vg_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            f2_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
-            f2_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            vx_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
+            vx_bfly4<true>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            f2_tw3<true>(a[r + 4], a[r + 8], a[r + 12], g2_tw(t_lo, t_hi, (j0 + Q * r) * step1));
-            f2_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
+            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], vg_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < 16; m++) s[G2_P(pos0 + Q * m)] = a[m];
+    for (int m = 0; m < 16; m++) vx_st(&s[G2_P(pos0 + Q * m)], a[m]);
 }
 
 // the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
@@ -2311,9 +2363,9 @@ __device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int p = tt + 512 * r;
-        const float2 a = s[G2_P(2 * p)], b = s[G2_P(2 * p + 1)];
-        s[G2_P(2 * p)] = make_float2(a.x + b.x, a.y + b.y);
-        s[G2_P(2 * p + 1)] = make_float2(a.x - b.x, a.y - b.y);
+        const v2f a = vx_ld(&s[G2_P(2 * p)]), b = vx_ld(&s[G2_P(2 * p + 1)]);
+        vx_st(&s[G2_P(2 * p)], a + b);
+        vx_st(&s[G2_P(2 * p + 1)], a - b);
     }
 }
 
@@ -2411,29 +2463,29 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
     g2_forward<false>(s[half], t_lo, t_hi, tt);
     // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers - the pairs of the
     // transforms' radix-2 stage, which is applied here on the way in and on the way out
-    float2 yl[8], yr[8];
+    v2f yl[8], yr[8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int j = threadIdx.x + G2_THREADS * r;
         asm volatile("" : "+v"(j));  // addresses of this group are formed here, not ahead of the transforms
         const int idx = 2 * j;
-        float2 aL0 = make_float2(0.f, 0.f), aL1 = aL0, aR0 = aL0, aR1 = aL0;
+        v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
-            float2 S0, S1;
+            v2f S0, S1;
             if (var) {
                 // -f and -(f + N/2) are a pair again (usually in the other order)
                 const int m0 = g2_mirror(idx), m1 = g2_mirror(idx + 1);
-                const float2 a = s[i][G2_P(m0 & ~1)], b = s[i][G2_P(m0 | 1)];
-                const float2 sum = make_float2(a.x + b.x, a.y + b.y), dif = make_float2(a.x - b.x, a.y - b.y);
+                const v2f a = vx_ld(&s[i][G2_P(m0 & ~1)]), b = vx_ld(&s[i][G2_P(m0 | 1)]);
+                const v2f sum = a + b, dif = a - b;
                 S0 = (m0 & 1) ? dif : sum;
                 S1 = (m1 & 1) ? dif : sum;
                 S0.y = -S0.y;
                 S1.y = -S1.y;
             } else {
-                const float2 a = s[i][G2_P(idx)], b = s[i][G2_P(idx + 1)];
-                S0 = make_float2(a.x + b.x, a.y + b.y);
-                S1 = make_float2(a.x - b.x, a.y - b.y);
+                const v2f a = vx_ld(&s[i][G2_P(idx)]), b = vx_ld(&s[i][G2_P(idx + 1)]);
+                S0 = a + b;
+                S1 = a - b;
             }
             const size_t row = (size_t)(var ? 256 : bin) * G2_N;
 #pragma unroll
@@ -2443,32 +2495,26 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                 const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
                 const float4 HL = reinterpret_cast<const float4*>(h + row)[j];
                 const float4 HR = reinterpret_cast<const float4*>(h + row + (size_t)257 * G2_N)[j];
-                const float2 pl0 = f2_mul(S0, make_float2(HL.x, HL.y)), pl1 = f2_mul(S1, make_float2(HL.z, HL.w));
-                const float2 pr0 = f2_mul(S0, make_float2(HR.x, HR.y)), pr1 = f2_mul(S1, make_float2(HR.z, HR.w));
-                aL0.x = fmaf(gl, pl0.x, aL0.x);
-                aL0.y = fmaf(gl, pl0.y, aL0.y);
-                aL1.x = fmaf(gl, pl1.x, aL1.x);
-                aL1.y = fmaf(gl, pl1.y, aL1.y);
-                aR0.x = fmaf(gr, pr0.x, aR0.x);
-                aR0.y = fmaf(gr, pr0.y, aR0.y);
-                aR1.x = fmaf(gr, pr1.x, aR1.x);
-                aR1.y = fmaf(gr, pr1.y, aR1.y);
+                aL0 += gl * vx_mul(S0, v2f{HL.x, HL.y});
+                aL1 += gl * vx_mul(S1, v2f{HL.z, HL.w});
+                aR0 += gr * vx_mul(S0, v2f{HR.x, HR.y});
+                aR1 += gr * vx_mul(S1, v2f{HR.z, HR.w});
             }
         }
-        yl[2 * r] = make_float2(aL0.x + aL1.x, aL0.y + aL1.y);
-        yl[2 * r + 1] = make_float2(aL0.x - aL1.x, aL0.y - aL1.y);
-        yr[2 * r] = make_float2(aR0.x + aR1.x, aR0.y + aR1.y);
-        yr[2 * r + 1] = make_float2(aR0.x - aR1.x, aR0.y - aR1.y);
+        yl[2 * r] = aL0 + aL1;
+        yl[2 * r + 1] = aL0 - aL1;
+        yr[2 * r] = aR0 + aR1;
+        yr[2 * r + 1] = aR0 - aR1;
         asm volatile("" ::: "memory");  // one group of loads in flight at a time: keeps the kernel free of spills
     }
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int idx = 2 * (threadIdx.x + G2_THREADS * r);
-        s[0][G2_P(idx)] = yl[2 * r];
-        s[0][G2_P(idx + 1)] = yl[2 * r + 1];
-        s[1][G2_P(idx)] = yr[2 * r];
-        s[1][G2_P(idx + 1)] = yr[2 * r + 1];
+        vx_st(&s[0][G2_P(idx)], yl[2 * r]);
+        vx_st(&s[0][G2_P(idx + 1)], yl[2 * r + 1]);
+        vx_st(&s[1][G2_P(idx)], yr[2 * r]);
+        vx_st(&s[1][G2_P(idx + 1)], yr[2 * r + 1]);
     }
     __syncthreads();
     g2_inverse<false>(s[half], t_lo, t_hi, tt);
