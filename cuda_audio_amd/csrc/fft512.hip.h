@@ -18,11 +18,45 @@
 #define FFT_ROW 72                       // padded row length (complex) of the exchange tile
 #define FFT_WAVE_LDS (8 * FFT_ROW)       // complex entries of wave-private LDS (>= 512)
 
+// Complex arithmetic on two-element vectors; the products and the +-j rotations are spelled out as the packed
+// instructions they are (operand swizzles and sign modifiers of v_pk_mul / v_pk_fma / v_pk_add) - from scalar
+// expressions the compiler re-packs them through register moves (262 instead of 144 VALU instructions for a
+// radix-16 pass of the second-level transforms, kernels.hip.h).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vx_of(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 vx_to(v2f a) { return make_float2(a.x, a.y); }
+// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ v2f vx_mul(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ v2f vx_mulc(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a - j b = (a.x + b.y, a.y - b.x) and a + j b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f vx_sub_j(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f vx_add_j(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + DIR j b (DIR = -1: forward transform, +1: inverse)
+template <int DIR>
+__device__ __forceinline__ v2f vx_rot(v2f a, v2f b) { return DIR < 0 ? vx_sub_j(a, b) : vx_add_j(a, b); }
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return vx_to(vx_mul(vx_of(a), vx_of(b))); }
 // multiply by -j (forward) or +j (inverse)
 template <int DIR>
 __device__ __forceinline__ float2 mulj(float2 a) {
@@ -33,31 +67,27 @@ __device__ __forceinline__ float2 mulj(float2 a) {
 template <int DIR>
 __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     const float h = 0.70710678118654752440f;
-    // even / odd 4-point DFTs
-    float2 e0 = cadd(v[0], v[4]), e1 = csub(v[0], v[4]);
-    float2 e2 = cadd(v[2], v[6]), e3 = mulj<DIR>(csub(v[2], v[6]));
-    float2 E0 = cadd(e0, e2), E2 = csub(e0, e2), E1 = cadd(e1, e3), E3 = csub(e1, e3);
-    float2 o0 = cadd(v[1], v[5]), o1 = csub(v[1], v[5]);
-    float2 o2 = cadd(v[3], v[7]), o3 = mulj<DIR>(csub(v[3], v[7]));
-    float2 O0 = cadd(o0, o2), O2 = csub(o0, o2), O1 = cadd(o1, o3), O3 = csub(o1, o3);
-    // twiddles w8^k, k = 1..3
-    float2 t1, t3;
-    if (DIR < 0) {
-        t1 = make_float2((O1.x + O1.y) * h, (O1.y - O1.x) * h);    // * (1 - j)/sqrt2
-        t3 = make_float2((-O3.x + O3.y) * h, (-O3.y - O3.x) * h);  // * (-1 - j)/sqrt2
-    } else {
-        t1 = make_float2((O1.x - O1.y) * h, (O1.y + O1.x) * h);    // * (1 + j)/sqrt2
-        t3 = make_float2((-O3.x - O3.y) * h, (-O3.y + O3.x) * h);  // * (-1 + j)/sqrt2
-    }
-    float2 t2 = mulj<DIR>(O2);
-    v[0] = cadd(E0, O0);
-    v[4] = csub(E0, O0);
-    v[1] = cadd(E1, t1);
-    v[5] = csub(E1, t1);
-    v[2] = cadd(E2, t2);
-    v[6] = csub(E2, t2);
-    v[3] = cadd(E3, t3);
-    v[7] = csub(E3, t3);
+    v2f x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = vx_of(v[r]);
+    // even / odd 4-point DFTs (w4 = DIR j)
+    const v2f e0 = x[0] + x[4], e1 = x[0] - x[4], e2 = x[2] + x[6], d2 = x[2] - x[6];
+    const v2f E0 = e0 + e2, E2 = e0 - e2, E1 = vx_rot<DIR>(e1, d2), E3 = vx_rot<-DIR>(e1, d2);
+    const v2f o0 = x[1] + x[5], o1 = x[1] - x[5], o2 = x[3] + x[7], d3 = x[3] - x[7];
+    const v2f O0 = o0 + o2, O2 = o0 - o2, O1 = vx_rot<DIR>(o1, d3), O3 = vx_rot<-DIR>(o1, d3);
+    // twiddles w8^k, k = 1..3: (1 + DIR j)/sqrt2, DIR j, (-1 + DIR j)/sqrt2
+    const v2f t1 = vx_rot<DIR>(O1, O1);   // O1 (1 + DIR j), scaled by h below
+    const v2f t3 = vx_rot<-DIR>(O3, O3);  // O3 (1 - DIR j) = -O3 (-1 + DIR j), scaled by -h below
+    x[0] = E0 + O0;
+    x[4] = E0 - O0;
+    x[1] = E1 + h * t1;
+    x[5] = E1 - h * t1;
+    x[2] = vx_rot<DIR>(E2, O2);
+    x[6] = vx_rot<-DIR>(E2, O2);
+    x[3] = E3 - h * t3;
+    x[7] = E3 + h * t3;
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = vx_to(x[r]);
 }
 
 template <int DIR>

@@ -1933,34 +1933,9 @@ __device__ __forceinline__ float2 f2_mul(float2 a, float2 b) { return make_float
 // instructions per radix-16 pass and thread.  From the same arithmetic on float2 structs the compiler re-packs scalar
 // operations through 70 register moves (262 instructions); from plain vector expressions it still materialises the
 // lane-wise negations (186).
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f vx_ld(const float2* p) { return *reinterpret_cast<const v2f*>(p); }
 __device__ __forceinline__ void vx_st(float2* p, v2f v) { *reinterpret_cast<v2f*>(p) = v; }
-// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
-__device__ __forceinline__ v2f vx_mul(v2f a, v2f b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-}
-// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
-__device__ __forceinline__ v2f vx_mulc(v2f a, v2f b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-}
-// a - j b = (a.x + b.y, a.y - b.x) and a + j b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2f vx_sub_j(v2f a, v2f b) {
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f vx_add_j(v2f a, v2f b) {
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// (v2f, vx_mul, vx_mulc, vx_add_j, vx_sub_j: fft512.hip.h)
 // radix-4 butterfly in place: forward y_m = sum_n a_n (-j)^(mn), inverse with +j
 template <bool INV>
 __device__ __forceinline__ void vx_bfly4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
