@@ -2217,7 +2217,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #pragma unroll 2
     for (int r = 0; r < R / 2; r++) {  // entries 2j, 2j + 1 per lane: 16-byte loads of the stash and the IR spectra
         const int j = threadIdx.x + F2_THREADS * r, idx = 2 * j;
-        float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0;
+        v2f acc0 = v2f{0.f, 0.f}, acc1 = acc0;
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
             const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N;
@@ -2225,29 +2225,26 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
             for (int vi = 0; vi < MC_MAXV; vi++) {
                 if (vi >= vv.n) break;
                 const float2* sq = my + (size_t)(per_slot ? vi * 4 + c * 2 + i : i) * F2_N;
-                float2 S0, S1;
+                v2f S0, S1;
                 if (var) {
-                    S0 = sq[f2_mirror(idx)];
-                    S1 = sq[f2_mirror(idx + 1)];
+                    S0 = vx_ld(sq + f2_mirror(idx));
+                    S1 = vx_ld(sq + f2_mirror(idx + 1));
                     S0.y = -S0.y;
                     S1.y = -S1.y;
                 } else {
                     const float4 S = reinterpret_cast<const float4*>(sq)[j];
-                    S0 = make_float2(S.x, S.y);
-                    S1 = make_float2(S.z, S.w);
+                    S0 = v2f{S.x, S.y};
+                    S1 = v2f{S.z, S.w};
                 }
                 const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
                 const float g = per_slot ? 1.0f : (c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w));
                 const float4 H = reinterpret_cast<const float4*>(h + row)[j];
-                const float2 p0 = f2_mul(S0, make_float2(H.x, H.y)), p1 = f2_mul(S1, make_float2(H.z, H.w));
-                acc0.x = fmaf(g, p0.x, acc0.x);
-                acc0.y = fmaf(g, p0.y, acc0.y);
-                acc1.x = fmaf(g, p1.x, acc1.x);
-                acc1.y = fmaf(g, p1.y, acc1.y);
+                acc0 += g * vx_mul(S0, v2f{H.x, H.y});
+                acc1 += g * vx_mul(S1, v2f{H.z, H.w});
             }
         }
-        s[F2_P(idx)] = acc0;
-        s[F2_P(idx + 1)] = acc1;
+        vx_st(&s[F2_P(idx)], acc0);
+        vx_st(&s[F2_P(idx + 1)], acc1);
     }
     __syncthreads();
     f2_inverse(s, t_lo, t_hi);
