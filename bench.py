@@ -69,8 +69,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--pipeline", action="store_true",
                     help="mc_config.pipeline: run the post stage of batch k on a second stream under the MAC of batch k + 1 "
-                         "(same output bits, ~3 %% more throughput with the second-level transform; off by default so that the "
-                         "dominant kernel is timed alone, as rocprofv3 sees it - overlapped, k_g2_mac's launches stretch to 0.141 ms)")
+                         "(same output bits; a few percent either way depending on the batch length - off by default, so that the "
+                         "dominant kernel is timed alone, as rocprofv3 sees it)")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
     ap.add_argument("--emulate-world", type=int, default=0,
