@@ -2275,6 +2275,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #define G2_P(i) ((i) + ((i) >> 5))
 #define G2_LDS (G2_N + G2_N / 32)
 #define G2_THREADS 1024
+#ifndef G2_PF
+#define G2_PF 2  // groups of product entries whose spectra are loaded together
+#endif
 
 __device__ __forceinline__ float2 g2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
 __device__ __forceinline__ v2f vg_tw(const float2* t_lo, const float2* t_hi, int e) { return vx_mul(vx_ld(t_lo + (e & 127)), vx_ld(t_hi + (e >> 7))); }
@@ -2437,47 +2440,69 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
     // transforms' radix-2 stage, which is applied here on the way in and on the way out
     v2f yl[8], yr[8];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int j = threadIdx.x + G2_THREADS * r;
-        asm volatile("" : "+v"(j));  // addresses of this group are formed here, not ahead of the transforms
-        const int idx = 2 * j;
-        v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
-        for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
-            const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
-            v2f S0, S1;
-            if (var) {
-                // -f and -(f + N/2) are a pair again (usually in the other order)
-                const int m0 = g2_mirror(idx), m1 = g2_mirror(idx + 1);
-                const v2f a = vx_ld(&s[i][G2_P(m0 & ~1)]), b = vx_ld(&s[i][G2_P(m0 | 1)]);
-                const v2f sum = a + b, dif = a - b;
-                S0 = (m0 & 1) ? dif : sum;
-                S1 = (m1 & 1) ? dif : sum;
-                S0.y = -S0.y;
-                S1.y = -S1.y;
-            } else {
-                const v2f a = vx_ld(&s[i][G2_P(idx)]), b = vx_ld(&s[i][G2_P(idx + 1)]);
-                S0 = a + b;
-                S1 = a - b;
-            }
-            const size_t row = (size_t)(var ? 256 : bin) * G2_N;
+    for (int rp = 0; rp < 4; rp += G2_PF) {
+        // the spectra of the first voice for G2_PF groups of entries at a time: 4 G2_PF loads of 16 bytes in flight per
+        // thread (requesting the first batch ahead of the window fill, or all four groups at once, was no faster)
+        float4 HLp[G2_PF][2], HRp[G2_PF][2];
 #pragma unroll
-            for (int vi = 0; vi < MC_MAXV; vi++) {
-                if (vi >= vv.n) break;
-                const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
-                const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
-                const float4 HL = reinterpret_cast<const float4*>(h + row)[j];
-                const float4 HR = reinterpret_cast<const float4*>(h + row + (size_t)257 * G2_N)[j];
-                aL0 += gl * vx_mul(S0, v2f{HL.x, HL.y});
-                aL1 += gl * vx_mul(S1, v2f{HL.z, HL.w});
-                aR0 += gr * vx_mul(S0, v2f{HR.x, HR.y});
-                aR1 += gr * vx_mul(S1, v2f{HR.z, HR.w});
+        for (int r2 = 0; r2 < G2_PF; r2++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                int j = threadIdx.x + G2_THREADS * (rp + r2);
+                asm volatile("" : "+v"(j));  // addresses of this group are formed here, not ahead of the transforms
+                const float2* h = (i == 0 ? vv.h0[0] : vv.h1[0]) + (size_t)bin * G2_N;
+                HLp[r2][i] = reinterpret_cast<const float4*>(h)[j];
+                HRp[r2][i] = reinterpret_cast<const float4*>(h + (size_t)257 * G2_N)[j];
             }
+#pragma unroll
+        for (int r2 = 0; r2 < G2_PF; r2++) {
+            const int r = rp + r2;
+            int j = threadIdx.x + G2_THREADS * r;
+            asm volatile("" : "+v"(j));
+            const int idx = 2 * j;
+            v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
+            for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
+                const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
+                v2f S0, S1;
+                if (var) {
+                    // -f and -(f + N/2) are a pair again (usually in the other order)
+                    const int m0 = g2_mirror(idx), m1 = g2_mirror(idx + 1);
+                    const v2f a = vx_ld(&s[i][G2_P(m0 & ~1)]), b = vx_ld(&s[i][G2_P(m0 | 1)]);
+                    const v2f sum = a + b, dif = a - b;
+                    S0 = (m0 & 1) ? dif : sum;
+                    S1 = (m1 & 1) ? dif : sum;
+                    S0.y = -S0.y;
+                    S1.y = -S1.y;
+                } else {
+                    const v2f a = vx_ld(&s[i][G2_P(idx)]), b = vx_ld(&s[i][G2_P(idx + 1)]);
+                    S0 = a + b;
+                    S1 = a - b;
+                }
+                const size_t row = (size_t)(var ? 256 : bin) * G2_N;
+#pragma unroll
+                for (int vi = 0; vi < MC_MAXV; vi++) {
+                    if (vi >= vv.n) break;
+                    const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
+                    const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
+                    float4 HL, HR;
+                    if (vi == 0 && !var) {
+                        HL = i == 0 ? HLp[r2][0] : HLp[r2][1];
+                        HR = i == 0 ? HRp[r2][0] : HRp[r2][1];
+                    } else {
+                        HL = reinterpret_cast<const float4*>(h + row)[j];
+                        HR = reinterpret_cast<const float4*>(h + row + (size_t)257 * G2_N)[j];
+                    }
+                    aL0 += gl * vx_mul(S0, v2f{HL.x, HL.y});
+                    aL1 += gl * vx_mul(S1, v2f{HL.z, HL.w});
+                    aR0 += gr * vx_mul(S0, v2f{HR.x, HR.y});
+                    aR1 += gr * vx_mul(S1, v2f{HR.z, HR.w});
+                }
+            }
+            yl[2 * r] = aL0 + aL1;
+            yl[2 * r + 1] = aL0 - aL1;
+            yr[2 * r] = aR0 + aR1;
+            yr[2 * r + 1] = aR0 - aR1;
         }
-        yl[2 * r] = aL0 + aL1;
-        yl[2 * r + 1] = aL0 - aL1;
-        yr[2 * r] = aR0 + aR1;
-        yr[2 * r + 1] = aR0 - aR1;
-        asm volatile("" ::: "memory");  // one group of loads in flight at a time: keeps the kernel free of spills
     }
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
 #pragma unroll
