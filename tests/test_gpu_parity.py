@@ -1352,10 +1352,13 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
     assert np.array_equal(outs[0], outs[1]), f"rms difference {rms(outs[0] - outs[1]):.3e}"
 
 
-def test_preferred_batch_length(gpu_lib):
+def test_preferred_batch_length(gpu_lib, monkeypatch):
     """mc_preferred_batch: whole chunks of the second-level transform for the longest loaded IR, minus one block,
     a multiple of 8, within at_most and max_batch; short limits come back as they are."""
     from cuda_audio_amd.synth import make_ir
+
+    monkeypatch.setenv("MCCONV_FFT2", "1")  # (the suite is also run with the measurement switches set)
+    monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
 
     c = _conv(fftSize=524288, max_batch=40000)
     assert c.preferred_batch(1000) == 1000  # nothing loaded: no preference
