@@ -2063,6 +2063,10 @@ __device__ __forceinline__ void f2_quads(float2* s, int t) {
 // natural order in, digit-reversed order out (unscaled forward transform); every pass moves the sequence through
 // registers in 1024 pieces of 16 elements
 #define F2_PIECES (F2_N / 16)
+// QUADS = false leaves the last stage (radix-4 on adjacent quads, no twiddles) to the caller: k_f2_prod applies it to
+// the quads a thread owns on the way into the products and its inverse on the way out (one trip through LDS less in
+// k_f2_fwd and one in k_f2_prod)
+template <bool QUADS = true>
 __device__ __forceinline__ void f2_forward(float2* s, const float2* t_lo, const float2* t_hi) {
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<false>(s, t_lo, t_hi, t, t, 10);  // quarter lengths 4096, 1024
     __syncthreads();
@@ -2072,14 +2076,19 @@ __device__ __forceinline__ void f2_forward(float2* s, const float2* t_lo, const 
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
         f2_pair<false>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);  // 16, 4
     __syncthreads();
-    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<false>(s, t);  // 1
-    __syncthreads();
+    if (QUADS) {
+        for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<false>(s, t);  // 1
+        __syncthreads();
+    }
 }
 
 // digit-reversed order in, natural order out (unscaled inverse: F2_N times the input sequence)
+template <bool QUADS = true>
 __device__ __forceinline__ void f2_inverse(float2* s, const float2* t_lo, const float2* t_hi) {
-    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<true>(s, t);
-    __syncthreads();
+    if (QUADS) {
+        for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<true>(s, t);
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
         f2_pair<true>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);
     __syncthreads();
@@ -2193,7 +2202,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_fwd(const float4* __restrict_
         s[F2_P(n)] = val;
     }
     __syncthreads();
-    f2_forward(s, t_lo, t_hi);
+    f2_forward<false>(s, t_lo, t_hi);  // the stash holds the sequence before the last stage, see k_f2_prod
     float4* my = reinterpret_cast<float4*>(stash + (((size_t)chunk * MC_NB + bin) * nseq + z) * F2_N);
 #pragma unroll
     for (int r = 0; r < R / 2; r++) {  // 16 bytes per lane: entries 2j, 2j + 1
@@ -2215,9 +2224,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
     const bool per_slot = nseq > 2;  // the stash holds gain-weighted sequences per voice and path
     f2_tables(t_lo, t_hi);
 #pragma unroll 2
-    for (int r = 0; r < R / 2; r++) {  // entries 2j, 2j + 1 per lane: 16-byte loads of the stash and the IR spectra
-        const int j = threadIdx.x + F2_THREADS * r, idx = 2 * j;
-        v2f acc0 = v2f{0.f, 0.f}, acc1 = acc0;
+    for (int r = 0; r < R / 4; r++) {  // a quad of entries 4j .. 4j + 3 per lane: the group of the transforms' last stage
+        const int j = threadIdx.x + F2_THREADS * r, idx = 4 * j;
+        v2f acc[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
         for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
             const int i = q & 1, var = q >> 1;  // var 1 (bin 0 only): the spectrum of conj(x_i) against h2
             const size_t row = ((size_t)c * 257 + (var ? 256 : bin)) * F2_N;
@@ -2225,29 +2234,41 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
             for (int vi = 0; vi < MC_MAXV; vi++) {
                 if (vi >= vv.n) break;
                 const float2* sq = my + (size_t)(per_slot ? vi * 4 + c * 2 + i : i) * F2_N;
-                v2f S0, S1;
+                // the stash holds the sequence before the last forward stage: finish it on the quad (for bin 0's second
+                // pass on the mirrored quad - the frequencies -f of a quad are a quad again, in another order)
+                const int m0 = var ? f2_mirror(idx) : idx;
+                const float4 Sa = reinterpret_cast<const float4*>(sq + (m0 & ~3))[0];
+                const float4 Sb = reinterpret_cast<const float4*>(sq + (m0 & ~3))[1];
+                v2f P0 = v2f{Sa.x, Sa.y}, P1 = v2f{Sa.z, Sa.w}, P2 = v2f{Sb.x, Sb.y}, P3 = v2f{Sb.z, Sb.w};
+                vx_bfly4<false>(P0, P1, P2, P3);
+                v2f S[4];
                 if (var) {
-                    S0 = vx_ld(sq + f2_mirror(idx));
-                    S1 = vx_ld(sq + f2_mirror(idx + 1));
-                    S0.y = -S0.y;
-                    S1.y = -S1.y;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int mk = f2_mirror(idx + k) & 3;
+                        v2f t = mk == 0 ? P0 : (mk == 1 ? P1 : (mk == 2 ? P2 : P3));
+                        t.y = -t.y;
+                        S[k] = t;
+                    }
                 } else {
-                    const float4 S = reinterpret_cast<const float4*>(sq)[j];
-                    S0 = v2f{S.x, S.y};
-                    S1 = v2f{S.z, S.w};
+                    S[0] = P0, S[1] = P1, S[2] = P2, S[3] = P3;
                 }
                 const float2* h = i == 0 ? vv.h0[vi] : vv.h1[vi];
                 const float g = per_slot ? 1.0f : (c == 0 ? (i == 0 ? vv.g[vi].x : vv.g[vi].y) : (i == 0 ? vv.g[vi].z : vv.g[vi].w));
-                const float4 H = reinterpret_cast<const float4*>(h + row)[j];
-                acc0 += g * vx_mul(S0, v2f{H.x, H.y});
-                acc1 += g * vx_mul(S1, v2f{H.z, H.w});
+                const float4 Ha = reinterpret_cast<const float4*>(h + row + idx)[0];
+                const float4 Hb = reinterpret_cast<const float4*>(h + row + idx)[1];
+                acc[0] += g * vx_mul(S[0], v2f{Ha.x, Ha.y});
+                acc[1] += g * vx_mul(S[1], v2f{Ha.z, Ha.w});
+                acc[2] += g * vx_mul(S[2], v2f{Hb.x, Hb.y});
+                acc[3] += g * vx_mul(S[3], v2f{Hb.z, Hb.w});
             }
         }
-        vx_st(&s[F2_P(idx)], acc0);
-        vx_st(&s[F2_P(idx + 1)], acc1);
+        vx_bfly4<true>(acc[0], acc[1], acc[2], acc[3]);  // the inverse transform's first stage
+#pragma unroll
+        for (int k = 0; k < 4; k++) vx_st(&s[F2_P(idx + k)], acc[k]);
     }
     __syncthreads();
-    f2_inverse(s, t_lo, t_hi);
+    f2_inverse<false>(s, t_lo, t_hi);
     const float sc = 1.0f / (float)F2_N;
     float2* dst = reinterpret_cast<float2*>(Yc + (size_t)bin * ycap + t_c0) + c;  // .xy = Y_L, .zw = Y_R
     for (int t = threadIdx.x; t < nout; t += F2_THREADS) {
