@@ -553,7 +553,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"stereo 44.1 kHz, 256-frame blocks, {a.taps}-tap IR ({P} partitions, N_ref {a.fft_size}), "
-                            f"2x2 path matrix, {T} blocks per step, {a.mode} MAC kernel",
+                            f"2x2 path matrix, {T} blocks per step, "
+                            + ("IR spectra re-read for every block (streaming MAC)" if a.mode == "stream" else
+                               "IR resident across the batch (sum over partitions: " + str(roofline.get("kernel")) + ")"),
                 "blocks_per_step": T,
                 "partitions": P,
                 "paths": 4,
