@@ -1352,6 +1352,38 @@ def test_pipelined_batches_equal_unpipelined(gpu_lib, n_ref, taps, T, pd, sliced
     assert np.array_equal(outs[0], outs[1]), f"rms difference {rms(outs[0] - outs[1]):.3e}"
 
 
+def test_overlap_add_in_the_inverse_kernel_is_bit_identical(gpu_lib, monkeypatch):
+    """Whole-batch path: k_inv_wet (inverse transform + overlap-add into the wet ring, tiles of 15 blocks + the block
+    before them) against k_inv + segment ring + overlap-add in k_post (MCCONV_INV_WET=0) - the same bits, for batch
+    lengths around the tile size, with a predelay, single periods in between and a predelay change."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    sizes = [1, 14, 15, 16, 1, 17, 29, 30, 31, 1, 1, 45, 46, 300, 7]
+    nb = sum(sizes)
+    x = make_input(nb * 256)
+    irs = [make_ir(5000, seed=11, norm=0.05), make_ir(4000, seed=12, norm=0.05)]
+
+    def run(flag):
+        monkeypatch.setenv("MCCONV_INV_WET", flag)
+        c = _conv(fftSize=8192, max_batch=max(sizes))
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, dict(BASE, predelay=700, wet=0.8), dict(BASE, select=1, level=0.9), False)
+        parts, o = [], 0
+        for k, n in enumerate(sizes):
+            if k == 9:
+                c.cc[0].value.predelay = 300
+            seg = x[:, o * 256:(o + n) * 256]
+            parts.append(np.stack(c.onProcess(seg[0], seg[1])) if n == 1 else c.process(seg[0], seg[1]))
+            o += n
+        c.close()
+        return np.concatenate(parts, axis=1)
+
+    a, b = run("1"), run("0")
+    assert rms(a) > 1e-3
+    assert np.array_equal(a, b), f"max abs difference {np.abs(a - b).max():.3e}"
+
+
 def test_preferred_batch_length(gpu_lib, monkeypatch):
     """mc_preferred_batch: whole chunks of the second-level transform for the longest loaded IR, minus one block,
     a multiple of 8, within at_most and max_batch; short limits come back as they are."""
