@@ -2296,6 +2296,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #define G2_P(i) ((i) + ((i) >> 5))
 #define G2_LDS (G2_N + G2_N / 32)
 #define G2_THREADS 1024
+#ifndef G2_PW
+#define G2_PW 4  // window rows (of 8) requested one item ahead in the persistent form of k_g2_mac
+#endif
 #ifndef G2_PF
 #define G2_PF 2  // groups of product entries whose spectra are loaded together
 #endif
@@ -2434,24 +2437,37 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__
 // grid = 256 bins x chunks, block = 1024 (two halves: input 1 / input 2, later Y_L / Y_R).
 // chunk_t + taps - 1 <= G2_N.
 __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
-                                                       int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap) {
+                                                       int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
     __shared__ float2 s[2][G2_LDS];
     __shared__ float2 t_lo[128], t_hi[64];
     // block ids 8 apart run on one XCD: there the chunks of a bin follow each other, so that the bin's second-level
     // spectra (262 KB for four paths) and the overlap of adjacent windows are read once into that XCD's L2
-    const int nch = gridDim.x >> 8, xq = blockIdx.x >> 3;
-    const int bin = (xq / nch) * 8 + (blockIdx.x & 7), chunk = xq % nch;
-    const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
-    const float4* fk = fdl + (size_t)bin * ring;
-    const int sb = slot0 + t_c0 - (taps - 1);
+    const int nch = nitems >> 8;
     const int half = threadIdx.x >> 9, tt = threadIdx.x & 511;
     g2_tables(t_lo, t_hi);
-    // the window, once: 16 bytes per slot carry both inputs
-#pragma unroll
-    for (int r = 0; r < G2_N / G2_THREADS; r++) {
+    // the window of an item, once: 16 bytes per slot carry both inputs.  G2_PW of its G2_N / G2_THREADS rows are requested
+    // one item ahead (before the inverse transform of the current item) and wait in registers.
+    float4 xw[G2_PW];
+    auto window_row = [&](int it, int r) -> float4 {
+        const int xq_ = it >> 3, bin_ = (xq_ / nch) * 8 + (it & 7), chunk_ = xq_ % nch;
+        const int t0_ = chunk_ * chunk_t, L = min(chunk_t, T - t0_) + taps - 1;
+        const float4* fk = fdl + (size_t)bin_ * ring;
+        const int sb = slot0 + t0_ - (taps - 1);
         const int n = threadIdx.x + G2_THREADS * r;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < L) x = fk[(sb + n) & (ring - 1)];
+        return x;
+    };
+#pragma unroll
+    for (int r = 0; r < G2_PW; r++) xw[r] = window_row(blockIdx.x, r);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int xq = item >> 3;
+    const int bin = (xq / nch) * 8 + (item & 7), chunk = xq % nch;
+    const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0);
+#pragma unroll
+    for (int r = 0; r < G2_N / G2_THREADS; r++) {
+        const int n = threadIdx.x + G2_THREADS * r;
+        const float4 x = r < G2_PW ? xw[r] : window_row(item, r);
         s[0][G2_P(n)] = make_float2(x.x, x.y);
         s[1][G2_P(n)] = make_float2(x.z, x.w);
     }
@@ -2535,6 +2551,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         vx_st(&s[1][G2_P(idx + 1)], yr[2 * r + 1]);
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) {
+#pragma unroll
+        for (int r = 0; r < G2_PW; r++) xw[r] = window_row(item + (int)gridDim.x, r);
+    }
     g2_inverse<false>(s[half], t_lo, t_hi, tt);
     const float sc = 1.0f / (float)G2_N;
     float4* dst = Yc + (size_t)bin * ycap + t_c0;
@@ -2542,4 +2562,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         const float2 a = s[0][G2_P(t + taps - 1)], b = s[1][G2_P(t + taps - 1)];
         dst[t] = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc);
     }
+    __syncthreads();  // the buffers are free for the next item
+  }
 }

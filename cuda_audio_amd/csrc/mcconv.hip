@@ -175,6 +175,7 @@ struct mc_engine {
     hipEvent_t ev_tail = nullptr;
     bool fft2 = true;     // long batches: second-level transform along the block axis instead of the MAC
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
+    int g2_grid = 256;       // workgroups of k_g2_mac: one per CU (set at create), each loops over its (bin, chunk) items; MCCONV_G2_GRID
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     bool inv_to_wet = true;  // whole-batch path: k_inv_wet + ring-reading k_post (MCCONV_INV_WET=0: k_inv + segment ring)
@@ -767,8 +768,8 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 }
                 const int chunk_t = G2_N - pmax + 1;
                 const int nch = (T + chunk_t - 1) / chunk_t;
-                hipLaunchKernelGGL(k_g2_mac, dim3(MC_NB * nch), dim3(G2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax,
-                                   vv, e->d_Yc, e->Tcap);
+                hipLaunchKernelGGL(k_g2_mac, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0,
+                                   T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
                 mo->ysrc = e->d_Yc;
                 mo->sk = e->Tcap;
                 mo->stt = 1;
@@ -1685,6 +1686,11 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) e->g2_grid = cus & ~7;
+    }
+    if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(8, std::atoi(gg) & ~7);
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
