@@ -4,23 +4,35 @@
 Workload (BASELINE.json configs[2], the one the metric is quoted on): stereo
 44.1 kHz, 256-frame blocks, 10 s / 441 000-tap IR (P = 1723 partitions,
 N_ref = 524288), reference routing (2 inputs x 2 outputs = 4 convolution
-paths), fp32.  One "step" = one batch of --blocks (default: the engine's preferred length, 32320) consecutive blocks pushed
-through forward FFT -> partition x bin MAC -> inverse FFT -> overlap-add ->
-predelay / Q1-Q2 terms / clamp / dry mix, inputs and outputs resident in HBM.
+paths), fp32.  One "step" = one batch of --blocks (default: the engine's
+preferred length, 32320) consecutive blocks pushed through forward FFT ->
+sum over partitions -> inverse FFT -> overlap-add -> predelay / Q1-Q2 terms /
+clamp / dry mix, inputs and outputs resident in HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1, default (--shard blocks): every GPU holds the whole IR set and is fed the
-same batch of N x --blocks blocks; rank r finishes output blocks [r, r + 1) x
---blocks of it - independent units, no data-path collective, weak scaling.
---shard partitions: IR partitions sharded over the ranks, the partial wet blocks
-summed with an RCCL reduce (the layout that also shortens one real-time period).
+N = 1: the line also carries `parity` (the last timed step's output against the
+CPU oracle, same run), `roofline` (compulsory bytes of the dominant kernel /
+its event-bracketed duration), `host_io` (the same path with pinned host
+buffers in and out, PCIe-inclusive), `latency_mode` (one JACK period per call)
+and `cpu_baseline`.
+
+N > 1 measures BOTH multi-GPU layouts in the same run (each with an untimed
+check against an unsharded engine):
+  * output blocks sliced over the GPUs, no data-path collective (weak scaling:
+    every GPU finishes --blocks blocks per step) -> `value`;
+  * IR partitions sharded over the GPUs + RCCL sum-reduce of the partial wet
+    blocks (BASELINE.json's north-star layout; strong scaling: the step stays
+    --blocks blocks) -> `north_star_layout`.
+--channels 8 runs BASELINE config 4: four stereo `Convolution` pairs
+(main.cu:31-39 makes one object per pair) per rank.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,6 +45,7 @@ FS = 44100
 BLOCK = 256
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # vector = f32-MFMA rate
+RMS_TOL = 1e-5            # BASELINE.json north star: <= 1e-5 RMS vs the float64 oracle
 
 
 def parse():
@@ -43,10 +56,11 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0,
                     help="blocks per step (batch length T). 0 (default): what the engine prefers up to 32768 blocks "
                          "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 32320 = 187.6 s "
-                         "of audio = five chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR; 8 block-sliced ranks "
-                         "then stay within mc_config.max_batch (262144)")
+                         "of audio = five chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
+    ap.add_argument("--channels", type=int, default=2, choices=[2, 4, 6, 8],
+                    help="2 per `Convolution` object (main.cu:31-39): 8 = BASELINE config 4, four pairs with their own IRs")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
                     help="resident: IR held on chip across the batch; stream: every block re-reads IR+delay line")
     ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
@@ -54,33 +68,38 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the 1-block-per-call (JACK) measurement")
-    ap.add_argument("--shard", choices=["blocks", "partitions"], default="blocks",
-                    help="N > 1. blocks: every GPU is fed the same batch and finishes its slice of the output blocks - no "
-                         "data-path collective, the slices are gathered to rank 0 (default: batch throughput). partitions: "
-                         "every GPU holds 1/N of the IR partitions and the partial wet blocks are summed with RCCL (the "
-                         "layout that also shortens a single real-time period)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the pinned-host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the same-run comparison with the CPU oracle")
+    ap.add_argument("--layouts", choices=["both", "blocks", "partitions"], default="both",
+                    help="N > 1: which multi-GPU layouts to measure (default both; `value` is the block-sliced one)")
     ap.add_argument("--exchange", choices=["gather", "none"], default="none",
-                    help="--shard blocks: leave every rank's finished slice on the GPU that computed it (default: like the "
-                         "inputs, the outputs of the batch path live in HBM; at ~150 GB/s of finished audio per GPU any "
-                         "funnel into one GPU is bound by its xGMI links, not by the convolution) or gather the slices "
-                         "on rank 0 over RCCL, overlapped with the next batch")
+                    help="block slices: leave every rank's finished slice on the GPU that computed it (default: like the "
+                         "inputs, the outputs of the batch path live in HBM) or gather the slices on rank 0 over RCCL")
     ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
-                    help="--shard partitions: sum of partial wet blocks to rank 0 (default) or to every rank")
+                    help="partition shards: sum of partial wet blocks to rank 0 (default) or to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--pipeline", action="store_true",
-                    help="mc_config.pipeline: run the post stage of batch k on a second stream under the MAC of batch k + 1 "
-                         "(same output bits; a few percent either way depending on the batch length - off by default, so that the "
-                         "dominant kernel is timed alone, as rocprofv3 sees it)")
+                    help="mc_config.pipeline: post stage of batch k on a second stream under the MAC of batch k + 1")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="with --force-sharded on one GPU: use the partition shard rank 0 of this many ranks would own")
+                    help="with --force-sharded on one GPU: be rank 0 of this many ranks (its slice / its partition shard)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1 collective backend. gloo is a rehearsal of the launch path on a box with fewer GPUs than "
                          "ranks (ranks share cards, the sum goes through host memory): never a headline number")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="use the partial / collective / finish path even with one rank (rehearsal on one GPU)")
+                    help="use the multi-GPU code paths even with one rank (rehearsal on one GPU)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed: run the step back to back for this long before the --warmup steps so that the timed region "
+                         "does not start on idle clocks (the driver's 20-step region is 6 ms long); reported in the line")
     return ap.parse_args()
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
 
 def cpu_threads():
@@ -116,7 +135,7 @@ def cpu_baseline(ir, ir_b, x, seconds):
     done = 0
     while time.perf_counter() - t0 < seconds:
         o = (done % max(avail - chunk, 1))
-        eng.process(x[0, o * BLOCK : (o + chunk) * BLOCK], x[1, o * BLOCK : (o + chunk) * BLOCK], g, g, threads)
+        eng.process(x[0, o * BLOCK: (o + chunk) * BLOCK], x[1, o * BLOCK: (o + chunk) * BLOCK], g, g, threads)
         done += chunk
     dt = time.perf_counter() - t0
     eng.close()
@@ -128,6 +147,115 @@ def cpu_baseline(ir, ir_b, x, seconds):
         "sample": f"{done} blocks ({done * BLOCK / FS:.1f} s of audio) of the same stereo/{ir.shape[0]}-tap workload, "
                   f"oracle/oracle.c orc_cpu32 (own radix-2 FFT, OpenMP over bins), {dt:.1f} s wall",
     }
+
+
+def oracle_parity(a, irs, params, excerpt, T, got, where):
+    """Same-run parity: blocks of the LAST timed step's output against the float64 oracle
+    (oracle.Upols.range, settled form: conv.cu:392-401 restated as the partitioned sum + Q1/Q2 terms).
+    excerpt = inputs of the previous and the last step ([2, 2 T 256]); got = the last step's output [2, T 256]."""
+    import oracle
+
+    num = den = sig = 0.0
+    nblk = 0
+    worst = 0.0
+    for b0, n in where:
+        u = oracle.Upols(a.fft_size, True)
+        for i, ir in enumerate(irs):
+            u.prepare(i, ir)
+        for h in (0, 1):
+            u.set(h, **params[h])
+        want = u.range(excerpt[0], excerpt[1], T + b0, n, settled=True)
+        u.close()
+        mine = got[:, b0 * BLOCK:(b0 + n) * BLOCK].astype(np.float64)
+        e = float(np.sqrt(np.mean((mine - want) ** 2)))
+        worst = max(worst, e)
+        num += float(((mine - want) ** 2).sum())
+        sig += float((want ** 2).sum())
+        den += want.size
+        nblk += n
+    rms_err, rms_sig = (num / den) ** 0.5, (sig / den) ** 0.5
+    return {"rms_err": rms_err, "rms_signal": rms_sig, "blocks": nblk, "tolerance": RMS_TOL, "ok": bool(rms_err <= RMS_TOL),
+            "worst_range_rms": worst,
+            "where": [f"[{b0}, {b0 + n})" for b0, n in where],
+            "oracle": "oracle/oracle.c orc_upols_range_settled (float64 partitioned form + Q1/Q2 window sums, pinned to the "
+                      "single-FFT restatement of conv.cu in tests/test_oracle.py), blocks of the last timed step"}
+
+
+def second_level_bytes(blk, taps, fused):
+    """Compulsory HBM bytes of one launch of the second-level transform over `blk` blocks: every delay-line slot of
+    the window once (16 B: both inputs), the four paths' second-level spectra once (a bin's chunks run together on one
+    XCD and share them in its L2), the partition sums written (16 B per block); the split form also parks its forward
+    transforms in a stash (written once, read once)."""
+    F2 = 8192 if fused else 16384
+    nchunk = -(-blk // (F2 - taps + 1))
+    window = 256 * 16 * (blk + taps - 1)
+    spectra = 256 * 4 * 8 * F2
+    sums = 256 * 16 * blk
+    stash = 0 if fused else 2 * (256 * 2 * 8 * F2 * nchunk)
+    return {"window": window, "spectra": spectra, "sums": sums, "stash": stash, "total": window + spectra + sums + stash,
+            "chunks": nchunk}
+
+
+def labelled_profile(name, key=None):
+    """A number copied from a committed profile is labelled as such: {value..., from, commit}.  None if absent."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        if key is not None:
+            d = d.get(key)
+        if d is None:
+            return None
+        try:
+            commit = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", os.path.join("profiles", name)],
+                                             stderr=subprocess.DEVNULL).decode().strip() or None
+        except Exception:
+            commit = None
+        return {"data": d, "from": "profiles/" + name, "commit": commit,
+                "note": "copied from a committed rocprofv3 profile of the same command, NOT measured in this run"}
+    except Exception:
+        return None
+
+
+class Pairs:
+    """The `Convolution` objects of one rank: one per stereo pair (main.cu:31-39).  Inputs / outputs are per pair."""
+
+    def __init__(self, a, local, npairs, T, **kw):
+        from cuda_audio_amd.engine import Convolution
+        from cuda_audio_amd.synth import make_ir
+
+        self.eng, self.irs = [], []
+        thr = (T + 1) if a.mode == "stream" else 0
+        for p in range(npairs):
+            e = Convolution(f"bench{p}", a.fft_size, max_batch=T, device=local, stream_threshold=min(thr, 16385),
+                            precision=a.precision, **kw)
+            # two distinct IRs per pair (seed 5678 + path, SURVEY 8(d)): in1 -> (L,R) through IR 0, in2 -> (L,R) through
+            # IR 1: four different convolution paths, no shared spectra; every pair has its own
+            irs = [make_ir(a.taps, seed=5678 + 4 * p), make_ir(a.taps, seed=5680 + 4 * p)]
+            e.prepare(0, irs[0])
+            e.prepare(1, irs[1])
+            for h in (0, 1):
+                e.cc[h].value.update(**bench_params(h))
+            self.eng.append(e)
+            self.irs.append(irs)
+
+    def __iter__(self):
+        return iter(self.eng)
+
+    def __getitem__(self, i):
+        return self.eng[i]
+
+    def __len__(self):
+        return len(self.eng)
+
+    def close(self):
+        for e in self.eng:
+            e.close()
+
+
+def bench_params(h):
+    return dict(select=h, predelay=0, dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
 
 
 def main():
@@ -142,14 +270,14 @@ def main():
     import torch.distributed as dist
 
     from cuda_audio_amd.engine import Convolution
+    from cuda_audio_amd.sharded import shard_bounds, slice_bounds
     from cuda_audio_amd.synth import make_input, make_ir
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if a.backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a card
         a.collective = "allreduce"                  # gloo has no reduce on device tensors
@@ -168,415 +296,545 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-
-    ir = make_ir(a.taps, seed=5678)
-    if a.blocks <= 0:
-        probe = Convolution("probe", a.fft_size, max_batch=32768, device=local)
-        probe.prepare(0, ir)
-        a.blocks = probe.preferred_batch(32768)
-        probe.close()
-    T = a.blocks
-    P = (min(a.taps, a.fft_size - 1024) + BLOCK - 1) // BLOCK
-    # shard bounds: multiples of 16 partitions
-    from cuda_audio_amd.sharded import shard_bounds
-
-    from cuda_audio_amd.sharded import slice_bounds
-
-    shard_world = world if world > 1 else (a.emulate_world if a.force_sharded and a.emulate_world > 1 else 1)
-    by_blocks = sharded and a.shard == "blocks"
-    if by_blocks:
-        # weak scaling: every rank finishes --blocks output blocks of a batch of N x --blocks
-        T = a.blocks * shard_world
-    first, count = slice_bounds(T, shard_world, rank) if by_blocks else (0, T)
-    if shard_world > 1 and not by_blocks:
-        pb, pe = shard_bounds(P, shard_world, rank)
-    else:
-        pb, pe = 0, 0
     if a.precision == "fp16":
         a.mode = "stream"
-    thr = (T + 1) if a.mode == "stream" else 0
-    # pipelined batches (the post stage of batch k under the MAC of batch k + 1) wherever no cross-GPU sum sits
-    # between the two halves of a batch
-    pipelined = a.pipeline and (not sharded or by_blocks) and a.precision == "fp32"
-    eng = Convolution("bench", a.fft_size, max_batch=T, device=local, part_begin=pb,
-                      part_end=pe if (shard_world > 1 and not by_blocks) else 0, stream_threshold=min(thr, 16385), precision=a.precision,
-                      pipeline=pipelined)
-    if shard_world > 1 and not by_blocks and pe == pb:
-        raise SystemExit("empty shard; use fewer ranks")
-    # two distinct IRs (seed 5678 + path): in1 -> (L,R) through IR 0, in2 -> (L,R) through IR 1,
-    # i.e. four different convolution paths, so the 4-path byte count has no shared spectra
-    ir_b = make_ir(a.taps, seed=5680)
-    eng.prepare(0, ir)
-    eng.prepare(1, ir_b)
-    for h in (0, 1):
-        eng.cc[h].value.update(select=h, predelay=0, dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
-
+    npairs = a.channels // 2
+    P = (min(a.taps, a.fft_size - 1024) + BLOCK - 1) // BLOCK
+    shard_world = world if world > 1 else (a.emulate_world if a.force_sharded and a.emulate_world > 1 else 1)
+    root_only = a.collective == "reduce"
     n_distinct = 4  # rotate through a few distinct input batches
-    xs = make_input(n_distinct * T * BLOCK, seed=1234)
-    d_in = torch.from_numpy(xs).to(dev)
-    d_out = torch.zeros(2, T * BLOCK, device=dev)
-    d_parts = [torch.zeros(2 * T * BLOCK, device=dev) for _ in range(2)] if (sharded and not by_blocks) else None
-    # block slices: this rank's output blocks of a batch (double-buffered), gathered on rank 0
-    d_slices = [torch.zeros(2, count * BLOCK, device=dev) for _ in range(3)] if by_blocks else None
-    d_gather = ([[torch.zeros(2, count * BLOCK, device=dev) for _ in range(world)] for _ in range(2)]
-                if by_blocks and rank == 0 and shard_world == world and a.exchange == "gather" else None)
-    # one compute stream for the engine, the torch ops and (as the stream the collectives order themselves
-    # against) RCCL: partial -> reduce -> finish are then ordered by the streams, not by host synchronisation
-    torch.cuda.synchronize()
     comp = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(comp)
-    eng.use_torch_stream(comp)
-    root_only = a.collective == "reduce"
-    pending = []
 
-    kept = None  # check mode: rank 0 keeps a copy of every finished batch
+    def preferred(pb=0, pe=0):
+        if a.blocks > 0:
+            return a.blocks
+        probe = Convolution("probe", a.fft_size, max_batch=32768, device=local, part_begin=pb, part_end=pe)
+        probe.prepare(0, make_ir(a.taps, seed=5678))
+        t = probe.preferred_batch(32768)
+        probe.close()
+        return t
 
-    def retire():
-        # second half of the oldest batch in flight: wait for its collective, then predelay / clamp / dry on the sum
-        work, part, i1, i2 = pending.pop(0)
-        work.wait()  # makes the compute stream wait for the collective; the host does not block
-        if rank == 0 or not root_only:
-            eng.finish_device(i1, i2, part.data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+    def timed(step, drain, steps, warmup, prewarm_ms=0.0, arm=None):
+        """prewarm (untimed, clocks), W warm-up steps, then exactly K steps bracketed by barrier + synchronize."""
+        npre = 0
+        if prewarm_ms > 0:
+            t0 = time.perf_counter()
+            while True:
+                for _ in range(8):
+                    step(npre)
+                    npre += 1
+                drain()
+                torch.cuda.synchronize()
+                go = (time.perf_counter() - t0) * 1e3 < prewarm_ms
+                if world > 1:  # every rank runs the same number of steps (they carry collectives)
+                    f = torch.tensor([1.0 if go else 0.0], device=dev)
+                    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                    go = bool(f.item() > 0.5)
+                if not go:
+                    break
+        for k in range(max(warmup, 1)):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        if arm:
+            arm()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, npre
+
+    def unsharded_reference(T, nchk, xs_dev, pair):
+        """rank 0: an unsharded engine fed the same batches from the same cold state (untimed checker)."""
+        full = Pairs(a, local, pair + 1, T)  # (engines 0 .. pair; only the last one is used: same IR seeds per pair)
+        e = full[pair]
+        e.use_torch_stream(comp)
+        outs = []
+        ref_out = torch.zeros(2, T * BLOCK, device=dev)
+        for k in range(nchk):
+            o = (k % n_distinct) * T * BLOCK
+            e.process_device(xs_dev[0, o:].data_ptr(), xs_dev[1, o:].data_ptr(), ref_out[0].data_ptr(), ref_out[1].data_ptr(), T)
+            torch.cuda.synchronize()
+            outs.append(ref_out.clone())
+        full.close()
+        return outs
+
+    def make_inputs(T):
+        xs = [make_input(n_distinct * T * BLOCK, seed=1234 + 10 * p) for p in range(npairs)]
+        return xs, [torch.from_numpy(x).to(dev) for x in xs]
+
+    # ------------------------------------------------------------------ single GPU
+    def run_single():
+        T = preferred()
+        eng = Pairs(a, local, npairs, T, pipeline=(a.pipeline and a.precision == "fp32"))
+        xs, d_in = make_inputs(T)
+        d_out = [torch.zeros(2, T * BLOCK, device=dev) for _ in range(npairs)]
+        torch.cuda.synchronize()
+        for e in eng:
+            e.use_torch_stream(comp)
+
+        def step(k):
+            o = (k % n_distinct) * T * BLOCK
+            for p, e in enumerate(eng):
+                e.process_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), d_out[p][0].data_ptr(), d_out[p][1].data_ptr(), T)
+
+        def drain():
+            if a.pipeline:
+                for e in eng:
+                    e.fence()
+
+        # kernel timing (HIP events on the launch stream around the dominant kernel) only during the timed steps
+        def arm():
+            eng[0].enable_kernel_timing(True)
+            eng[0].kernel_stats(reset=True)
+
+        t_pre = time.perf_counter()
+        dt, npre = timed(step, drain, a.steps, a.warmup, a.prewarm_ms, arm)
+        prewarm_s = time.perf_counter() - t_pre - dt
+        ks = eng[0].kernel_stats()
+        eng[0].enable_kernel_timing(False)
+
+        res = {"T": T, "dt": dt, "ks": ks,
+               "prewarm": {"steps": npre, "untimed_ms_before_the_timed_steps": round(prewarm_s * 1e3, 1),
+                           "note": "untimed: the step run back to back for --prewarm-ms before the --warmup steps, so that the "
+                                   "timed region does not start on idle clocks"}}
+        res["alg_bytes"] = eng[0].algorithmic_bytes_per_block()
+
+        # ---- same-run parity: the last timed step's output (pair 0) against the CPU oracle, untimed
+        if not a.no_parity:
+            last = (a.steps - 1) % n_distinct
+            prev = ((a.steps - 2) % n_distinct) if a.steps >= 2 else ((max(a.warmup, 1) - 1) % n_distinct)
+            reach = a.fft_size // BLOCK + 3
+            before = (npre + max(a.warmup, 1) + a.steps - 2) * T  # blocks of the stream before the excerpt
+            if a.precision != "fp32":
+                res["parity"] = {"skipped": "fp16 storage has its own bar (tests/test_gpu_parity.py: 2e-3 of the wet RMS)"}
+            elif T < reach + 64 or before < 400:
+                res["parity"] = {"skipped": f"steady-state excerpt needs batches of >= {reach + 64} blocks and a settled cross-fade"}
+            else:
+                x = xs[0]
+                excerpt = np.concatenate([x[:, prev * T * BLOCK:(prev + 1) * T * BLOCK], x[:, last * T * BLOCK:(last + 1) * T * BLOCK]], axis=1)
+                got = d_out[0].cpu().numpy()
+                chunk = None
+                lv = int(ks.get("fast_levels", 0))
+                if lv in (254, 255):
+                    chunk = (8192 if lv == 254 else 16384) - int(ks["partitions"]) + 1
+                where = [(0, 64)]  # first blocks of the launch: their windows and overlap-add reach into the previous step
+                if chunk and chunk + 32 < T:
+                    where.append((chunk - 32, 64))  # across the first chunk boundary of the second-level transform
+                where.append((T - 64, 64))  # the batch end
+                res["parity"] = oracle_parity(a, eng.irs[0], [bench_params(0), bench_params(1)], excerpt, T, got, where)
+
+        # ---- host-visible throughput (SURVEY 8(d) "output fully produced in host-visible memory"): pinned host
+        # buffers in and out through mc_process_batch, copies and kernels of consecutive chunks overlapped
+        if not a.no_host_io and a.mode == "resident" and npairs == 1:
+            e = eng[0]
+            e.set_stream(None)
+            nst = 6
+            hin, hout = e.pinned_array((2, nst * T * BLOCK)), e.pinned_array((2, nst * T * BLOCK))
+            for k in range(nst):
+                o = (k % n_distinct) * T * BLOCK
+                hin[:, k * T * BLOCK:(k + 1) * T * BLOCK] = xs[0][:, o:o + T * BLOCK]
+            e.process(hin[0, :2 * T * BLOCK], hin[1, :2 * T * BLOCK], hout[:, :2 * T * BLOCK])  # warm-up: staging buffers, streams
+            t1 = time.perf_counter()
+            e.process(hin[0], hin[1], hout)
+            dth = time.perf_counter() - t1
+            nb = nst * T
+            res["host_io"] = {
+                "rtf": round(nb * BLOCK / FS / dth, 1), "ms_per_block_batch": round(dth / nst * 1e3, 4), "blocks": nb,
+                "pcie_GBps_in": round(nb * 2 * BLOCK * 4 / dth / 1e9, 2), "pcie_GBps_out": round(nb * 2 * BLOCK * 4 / dth / 1e9, 2),
+                "note": "mc_process_batch with pinned host buffers (mc_host_alloc): one call over %d blocks, chunks of the "
+                        "engine's preferred batch, H2D / kernels / D2H of consecutive chunks on three streams; returns when the "
+                        "last output byte is in host memory. Never `value`." % nb,
+            }
+            e.use_torch_stream(comp)
+
+        # ---- latency mode (what JACK sees): one 256-frame period per mc_process call, host buffers in and out,
+        # the call returns when the output is on the host.  Called through ctypes with preallocated buffers.
+        if not a.no_latency and npairs == 1:
+            import ctypes as C
+
+            e = eng[0]
+            e.set_stream(None)
+            L = e._L
+            fp = C.POINTER(C.c_float)
+            x = xs[0]
+            bufs = [np.ascontiguousarray(x[0, :BLOCK]), np.ascontiguousarray(x[1, :BLOCK]),
+                    np.zeros(BLOCK, np.float32), np.zeros(BLOCK, np.float32)]
+            ptrs = [b.ctypes.data_as(fp) for b in bufs]
+            for _ in range(200):
+                L.mc_process(e._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
+            n_lat = 2000
+            t1 = time.perf_counter()
+            for _ in range(n_lat):
+                L.mc_process(e._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
+            lat = (time.perf_counter() - t1) / n_lat
+            # a second pass with HIP events around the sweep kernel (the events cost a few us of their own: not in `lat`)
+            e.enable_kernel_timing(True)
+            e.kernel_stats(reset=True)
+            for _ in range(500):
+                L.mc_process(e._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
+            ks1 = e.kernel_stats()
+            e.enable_kernel_timing(False)
+            k_ms = ks1["total_ms"] / max(ks1["launches"], 1)
+            ab = res["alg_bytes"]
+            latency = {
+                "us_per_block_wall": round(lat * 1e6, 2),
+                "rtf": round(BLOCK / FS / lat, 1),
+                "avg_runtime_ms": round(e.avgRuntime(), 5),
+                "mac_kernel": "k_mac_stream (every block re-reads 4 IR paths + 2 delay-line inputs: the literal partition x bin MAC)",
+                "mac_kernel_us_event_bracketed": round(k_ms * 1e3, 2),
+                "mac_algorithmic_GBps": round(ab / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                "mac_frac_of_hbm_peak": round(ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                "note": "all values measured in this run; event-bracketed single launches include ~3 us of event overhead. The "
+                        "21 MB working set is re-read every period and is served by L2 / Infinity Cache, not HBM "
+                        "(FETCH_SIZE of this launch: profiles/)",
+            }
+            longer = {}
+            for period in (512, 1024):
+                if T % (period // BLOCK):
+                    continue
+                e.set_period(period)
+                pb_ = [np.ascontiguousarray(x[0, :period]), np.ascontiguousarray(x[1, :period]),
+                       np.zeros(period, np.float32), np.zeros(period, np.float32)]
+                pp_ = [b.ctypes.data_as(fp) for b in pb_]
+                for _ in range(200):
+                    L.mc_process(e._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
+                t1 = time.perf_counter()
+                for _ in range(1000):
+                    L.mc_process(e._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
+                lp = (time.perf_counter() - t1) / 1000
+                longer[str(period)] = {"us_per_call_wall": round(lp * 1e6, 2), "rtf": round(period / FS / lp, 1)}
+            e.set_period(BLOCK)
+            latency["longer_periods"] = longer
+            res["latency_mode"] = latency
+
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(eng.irs[0][0], eng.irs[0][1], xs[0], a.cpu_seconds)
+        eng.close()
+        return res
+
+    # ------------------------------------------------------------------ multi GPU, layout 1: output blocks sliced
+    def run_blocks():
+        Tb = preferred()
+        T = Tb * shard_world  # weak scaling: every rank finishes Tb output blocks of a batch of N x Tb
+        first, count = slice_bounds(T, shard_world, rank)
+        pipelined = a.pipeline and a.precision == "fp32"
+        eng = Pairs(a, local, npairs, T, pipeline=pipelined)
+        xs, d_in = make_inputs(T)
+        d_slices = [[torch.zeros(2, count * BLOCK, device=dev) for _ in range(3)] for _ in range(npairs)]
+        gather = rank == 0 and shard_world == world and a.exchange == "gather"
+        d_gather = [[torch.zeros(2, count * BLOCK, device=dev) for _ in range(world)] for _ in range(2)] if gather else None
+        torch.cuda.synchronize()
+        for e in eng:
+            e.use_torch_stream(comp)
+        pending, ungathered = [], []
+        kept = None
+
+        class _Done:
+            def wait(self):
+                pass
+
+        def gather_slices(sl, k):
+            # the only exchange of the block-sliced layout: count * 2 KB per rank and batch to rank 0, off the data path
+            if shard_world != world or a.exchange == "none":
+                return _Done()
+            if a.backend == "gloo":  # rehearsal: through host memory
+                h = sl.cpu()
+                hl = [torch.zeros_like(h) for _ in range(world)] if rank == 0 else None
+                dist.gather(h, hl, dst=0)
+                if rank == 0:
+                    for g, t in zip(d_gather[k % 2], hl):
+                        g.copy_(t)
+                return _Done()
+            return dist.gather(sl, d_gather[k % 2] if rank == 0 else None, dst=0, async_op=True)
+
+        def retire_slices():
+            work, k = pending.pop(0)
+            work.wait()
             if kept is not None and rank == 0:
-                kept.append(d_out.clone())
-        else:
-            eng.finish_device(None, None, None, None, None, T)
+                kept.append(torch.cat(d_gather[k % 2], dim=1) if d_gather is not None else d_slices[0][k % 3].clone())
 
-    class _Done:
-        def wait(self):
-            pass
+        def hand_over(older_only):
+            if pipelined:
+                for e in eng:
+                    e.fence_older() if older_only else e.fence()
+            keep = ungathered[-1:] if older_only else []
+            for j in ungathered[:len(ungathered) - len(keep)]:
+                while len(pending) >= 2:  # the gather buffers are two deep
+                    retire_slices()
+                pending.append((gather_slices(d_slices[0][j % 3], j), j))
+            ungathered[:] = keep
 
-    def gather_slices(sl, k):
-        # the only exchange of the block-sliced layout: count * 2 KB per rank and batch to rank 0, off the data path
-        if shard_world != world or a.exchange == "none":  # (one emulated rank of several: nothing to gather)
-            return _Done()
-        if a.backend == "gloo":  # rehearsal: through host memory
-            h = sl.cpu()
-            hl = [torch.zeros_like(h) for _ in range(world)] if rank == 0 else None
-            dist.gather(h, hl, dst=0)
-            if rank == 0:
-                for g, t in zip(d_gather[k % 2], hl):
-                    g.copy_(t)
-            return _Done()
-        return dist.gather(sl, d_gather[k % 2] if rank == 0 else None, dst=0, async_op=True)
-
-    def retire_slices():
-        work, k = pending.pop(0)
-        work.wait()
-        if kept is not None and rank == 0:
-            kept.append(torch.cat(d_gather[k % 2], dim=1) if d_gather is not None else d_slices[k % 3].clone())
-
-    ungathered = []  # batches whose slices are computed (or in the pipeline) but not handed to the gather yet
-
-    def hand_over(older_only):
-        # the engine's stream waits for the post stage of the batches to be gathered - for all of them at the end,
-        # for all but the newest during the run (so that the next batch's MAC is not queued behind that post stage)
-        if pipelined:
-            eng.fence_older() if older_only else eng.fence()
-        keep = ungathered[-1:] if older_only else []
-        for j in ungathered[:len(ungathered) - len(keep)]:
-            while len(pending) >= 2:  # the gather buffers are two deep
-                retire_slices()
-            pending.append((gather_slices(d_slices[j % 3], j), j))
-        ungathered[:] = keep
-
-    def step(k):
-        o = (k % n_distinct) * T * BLOCK
-        i1, i2 = d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr()
-        if not sharded:
-            eng.process_device(i1, i2, d_out[0].data_ptr(), d_out[1].data_ptr(), T)
-            return
-        if by_blocks:
-            # at most two gathers in flight; the slice buffer of batch k - 3 is free once its gather has been waited for
+        def step(k):
+            o = (k % n_distinct) * T * BLOCK
             while len(pending) > (0 if a.no_overlap else 1):
                 retire_slices()
-            sl = d_slices[k % 3]
-            eng.process_slice_device(i1, i2, sl[0].data_ptr(), sl[1].data_ptr(), T, first, count)
+            for p, e in enumerate(eng):
+                sl = d_slices[p][k % 3]
+                e.process_slice_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), sl[0].data_ptr(), sl[1].data_ptr(), T, first, count)
             ungathered.append(k)
             hand_over(older_only=pipelined and not a.no_overlap)
             if a.no_overlap:
                 while pending:
                     retire_slices()
-            return
-        part = d_parts[k % 2]
-        eng.partial_device(i1, i2, part.data_ptr(), T)
-        if root_only:
-            work = dist.reduce(part, dst=0, async_op=True)
-        else:
-            work = dist.all_reduce(part, async_op=True)
-        # the reduce of batch k overlaps the MAC of batch k+1: batch k-1 is finished now
-        if pending and not a.no_overlap:
-            retire()
-        pending.append((work, part, i1, i2))
-        if a.no_overlap:
-            retire()
 
-    def drain():
-        if by_blocks:
+        def drain():
             hand_over(older_only=False)
-        elif pipelined:
-            eng.fence()
-        while pending:
-            retire_slices() if by_blocks else retire()
+            while pending:
+                retire_slices()
 
-    # settle the cold-start cross-fade (Q7) so the timed region is steady state
-    for k in range(max(a.warmup, 1)):
-        step(k)
-    drain()
-    torch.cuda.synchronize()
-    eng.enable_kernel_timing(True)
-    eng.kernel_stats(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(k)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ks = eng.kernel_stats()
-    eng.enable_kernel_timing(False)
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    blocks = a.steps * T
-    rtf = blocks * BLOCK / FS / dt
-    alg_bytes = eng.algorithmic_bytes_per_block()  # this rank's share
-    kern_s = ks["total_ms"] * 1e-3
-    kern_avg_ms = ks["total_ms"] / max(ks["launches"], 1)
-    achieved_gbs = alg_bytes * ks["blocks"] / kern_s / 1e9 if kern_s > 0 else 0.0
-    flops_per_block = 8.0 * 4 * ks["partitions"] * 256  # complex MAC = 8 flop, 4 paths
-    achieved_tf = flops_per_block * ks["blocks"] / kern_s / 1e12 if kern_s > 0 else 0.0
-
-    # latency mode (what JACK sees): one 256-frame period per mc_process call, host buffers in and out,
-    # the call returns when the output is on the host.  Called through ctypes with preallocated buffers
-    # so that the harness adds microseconds, not the tens of microseconds of numpy allocations.
-    latency = None
-    if rank == 0 and not sharded and not a.no_latency:
-        import ctypes as C
-
-        eng.set_stream(None)
-        L = eng._L
-        fp = C.POINTER(C.c_float)
-        bufs = [np.ascontiguousarray(xs[0, :BLOCK]), np.ascontiguousarray(xs[1, :BLOCK]),
-                np.zeros(BLOCK, np.float32), np.zeros(BLOCK, np.float32)]
-        ptrs = [b.ctypes.data_as(fp) for b in bufs]
-        for _ in range(200):
-            L.mc_process(eng._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
-        eng.enable_kernel_timing(True)
-        eng.kernel_stats(reset=True)
-        n_lat = 2000
-        t1 = time.perf_counter()
-        for _ in range(n_lat):
-            L.mc_process(eng._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
-        lat = (time.perf_counter() - t1) / n_lat
-        ks1 = eng.kernel_stats()
-        eng.enable_kernel_timing(False)
-        k_ms = ks1["total_ms"] / max(ks1["launches"], 1)
-        # rocprofv3 duration of the same kernel in the same path, from the committed profile of this round
-        prof_us = None
-        try:
-            import csv
-
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_jack_kernel_stats.csv"))))
-            tot = sum(float(r["TotalDurationNs"]) for r in rows if "k_mac_stream" in r["Name"])
-            cnt = sum(int(r["Calls"]) for r in rows if "k_mac_stream" in r["Name"])
-            prof_us = tot / cnt / 1e3 if cnt else None
-        except Exception:
-            prof_us = None
-        latency = {
-            "us_per_block_wall": round(lat * 1e6, 2),
-            "rtf": round(BLOCK / FS / lat, 1),
-            "avg_runtime_ms": round(eng.avgRuntime(), 5),
-            "mac_kernel": "k_mac_stream (every block re-reads 4 IR paths + 2 delay-line inputs)",
-            "mac_kernel_us_event_bracketed": round(k_ms * 1e3, 2),
-            "mac_achieved_GBps": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
-            "mac_frac_of_hbm_peak": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
-            "mac_kernel_us_rocprofv3": round(prof_us, 2) if prof_us else None,
-            "mac_achieved_GBps_rocprofv3": round(alg_bytes / (prof_us * 1e-6) / 1e9, 1) if prof_us else None,
-            "mac_frac_of_hbm_peak_rocprofv3": round(alg_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof_us else None,
-            "note": "event-bracketed single launches include ~3 us of event overhead; the rocprofv3 figure is the "
-                    "kernel's average duration in profiles/r1_jack_kernel_stats.csv (same path, same IRs)",
-        }
-        # the periods the reference's run scripts start jackd with (512 / 1024 frames per call)
-        longer = {}
-        for period in (512, 1024):
-            if T % (period // BLOCK):
-                continue
-            eng.set_period(period)
-            pb_ = [np.ascontiguousarray(xs[0, :period]), np.ascontiguousarray(xs[1, :period]),
-                   np.zeros(period, np.float32), np.zeros(period, np.float32)]
-            pp_ = [b.ctypes.data_as(fp) for b in pb_]
-            for _ in range(200):
-                L.mc_process(eng._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
-            t1 = time.perf_counter()
-            for _ in range(1000):
-                L.mc_process(eng._h, pp_[0], pp_[1], pp_[2], pp_[3], period)
-            lp = (time.perf_counter() - t1) / 1000
-            longer[str(period)] = {"us_per_call_wall": round(lp * 1e6, 2), "rtf": round(period / FS / lp, 1)}
-        eng.set_period(BLOCK)
-        latency["longer_periods"] = longer
-
-    # Untimed: the sharded pipeline exactly as timed above (two batches in flight, collective on RCCL's stream)
-    # against an unsharded engine fed the same batches from the same cold state, on rank 0.
-    sharded_check = None
-    if sharded and not a.no_check:
-        eng.reset()
-        kept = []
-        nchk = 3
-        for k in range(nchk):
-            step(k)
-        drain()
-        torch.cuda.synchronize()
-        if rank == 0:
-            full = Convolution("check", a.fft_size, max_batch=T, device=local, stream_threshold=min(thr, 16385),
-                               precision=a.precision)
-            full.prepare(0, ir)
-            full.prepare(1, ir_b)
-            for h in (0, 1):
-                full.cc[h].value.update(select=h, predelay=0, dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
-            full.use_torch_stream(comp)
-            ref_out = torch.zeros_like(d_out)
-            num = den = 0.0
+        dt, npre = timed(step, drain, a.steps, a.warmup, a.prewarm_ms)
+        res = {"T": T, "count": count, "dt": dt, "rtf": a.steps * T * BLOCK / FS / dt, "prewarm_steps": npre}
+        if not a.no_check:
+            for e in eng:
+                e.reset()
+            kept = []
+            nchk = 3
             for k in range(nchk):
-                o = (k % n_distinct) * T * BLOCK
-                full.process_device(d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr(), ref_out[0].data_ptr(), ref_out[1].data_ptr(), T)
-                torch.cuda.synchronize()
-                want = ref_out if kept[k].shape == ref_out.shape else ref_out[:, first * BLOCK:(first + count) * BLOCK]
-                num += float(((kept[k] - want).double() ** 2).sum())
-                den += float((want.double() ** 2).sum())
-            n_el = nchk * kept[0].numel()
-            sharded_check = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
-            full.close()
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            if rank == 0:
+                refs = unsharded_reference(T, nchk, d_in[0], 0)
+                num = den = 0.0
+                for k in range(nchk):
+                    want = refs[k] if kept[k].shape == refs[k].shape else refs[k][:, first * BLOCK:(first + count) * BLOCK]
+                    num += float(((kept[k] - want).double() ** 2).sum())
+                    den += float((want.double() ** 2).sum())
+                n_el = nchk * kept[0].numel()
+                res["sharded_check"] = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
+            kept = None
+            if world > 1:
+                dist.barrier()
+        eng.close()
+        return res
+
+    # ------------------------------------------------------------------ multi GPU, layout 2: IR partitions sharded + RCCL sum
+    def run_partitions():
+        pb, pe = shard_bounds(P, shard_world, rank)
+        if pe <= pb:
+            raise SystemExit("empty shard; use fewer ranks")
+        T = preferred(*shard_bounds(P, shard_world, 0))  # the same batch length on every rank: rank 0's shard decides
+        eng = Pairs(a, local, npairs, T, part_begin=pb, part_end=pe)
+        xs, d_in = make_inputs(T)
+        d_out = [torch.zeros(2, T * BLOCK, device=dev) for _ in range(npairs)]
+        # the partial wet blocks of all pairs of a rank travel in ONE collective per batch
+        d_parts = [torch.zeros(npairs, 2 * T * BLOCK, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        for e in eng:
+            e.use_torch_stream(comp)
+        pending = []
         kept = None
-        if world > 1:
-            dist.barrier()
 
-    cpu = None
-    if rank == 0 and not sharded and not a.no_cpu_baseline:
-        cpu = cpu_baseline(ir, ir_b, xs, a.cpu_seconds)
+        def retire():
+            work, part, o = pending.pop(0)
+            work.wait()  # makes the compute stream wait for the collective; the host does not block
+            for p, e in enumerate(eng):
+                if rank == 0 or not root_only:
+                    e.finish_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), part[p].data_ptr(),
+                                    d_out[p][0].data_ptr(), d_out[p][1].data_ptr(), T)
+                else:
+                    e.finish_device(None, None, None, None, None, T)
+            if kept is not None and rank == 0:
+                kept.append(d_out[0].clone())
 
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tj):
-        try:
-            traffic = json.load(open(tj)).get(a.mode)
-        except Exception:
-            traffic = None
+        def step(k):
+            o = (k % n_distinct) * T * BLOCK
+            part = d_parts[k % 2]
+            for p, e in enumerate(eng):
+                e.partial_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), part[p].data_ptr(), T)
+            if root_only:
+                work = dist.reduce(part, dst=0, async_op=True)
+            else:
+                work = dist.all_reduce(part, async_op=True)
+            # the reduce of batch k overlaps the kernels of batch k + 1: batch k - 1 is finished now
+            if pending and not a.no_overlap:
+                retire()
+            pending.append((work, part, o))
+            if a.no_overlap:
+                retire()
 
-    hbm_equiv = {
-        "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-        "algorithmic_bytes_per_block": alg_bytes,
-        "note": "SURVEY 8(d) accounting: every block re-reads 4 IR paths + 2 delay-line inputs; bytes x blocks / MAC kernel time",
+        def drain():
+            while pending:
+                retire()
+
+        dt, npre = timed(step, drain, a.steps, a.warmup, a.prewarm_ms)
+        lv = None
+        res = {"T": T, "dt": dt, "rtf": a.steps * T * BLOCK / FS / dt, "partitions_per_rank": pe - pb, "prewarm_steps": npre,
+               "reduce_bytes_per_step": int(npairs * 2 * T * BLOCK * 4)}
+        if not a.no_check:
+            for e in eng:
+                e.reset()
+            eng[0].enable_kernel_timing(True)
+            kept = []
+            nchk = 3
+            for k in range(nchk):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            lv = eng[0].kernel_stats()["fast_levels"]
+            eng[0].enable_kernel_timing(False)
+            if rank == 0:
+                refs = unsharded_reference(T, nchk, d_in[0], 0)
+                num = den = 0.0
+                for k in range(nchk):
+                    num += float(((kept[k] - refs[k]).double() ** 2).sum())
+                    den += float((refs[k].double() ** 2).sum())
+                n_el = nchk * kept[0].numel()
+                res["sharded_check"] = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
+            kept = None
+            if world > 1:
+                dist.barrier()
+        res["sum_over_partitions"] = {254: "second-level transform, fused form (k_g2_mac)", 255: "second-level transform, split form",
+                                      0: "direct-form MAC"}.get(lv, str(lv))
+        eng.close()
+        return res
+
+    # ------------------------------------------------------------------ assemble the line
+    workload = (f"{a.channels}-channel ({npairs} stereo pair(s), one Convolution object each) 44.1 kHz, 256-frame blocks, "
+                f"{a.taps}-tap IRs ({P} partitions, N_ref {a.fft_size}), 2x2 path matrix per pair")
+    line = {
+        "metric": "real-time factor (frames/s / 44.1k), stereo block=256, 10 s IR",
+        "unit": "x realtime",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "higher_is_better": True,
+        "vs_baseline": None,
+        "dtype": "f32" if a.precision == "fp32" else "f16 storage, f32 accumulate",
+        "data": "synthetic",
+        "head": git_head(),
     }
-    common = {"kernel": "k_mac_resident" if ks["resident"] else "k_mac_stream", "traffic": traffic,
-              "kernel_avg_ms": round(kern_avg_ms, 5), "kernel_launches": ks["launches"], "blocks_per_launch": (ks["blocks"] // max(ks["launches"], 1)) if ks["launches"] else T,
-              "flops_per_block": int(flops_per_block)}
-    if ks["resident"] and int(ks.get("fast_levels", 0)) in (254, 255):
-        # Second-level transform (k_f2_fwd + k_f2_prod): per (bin, chunk of blocks) one circular convolution of 16384 points.  Its
-        # own compulsory traffic per launch: the delay-line window of both inputs, the IRs' second-level spectra (four
-        # paths), the partition sums it writes; it is bound by memory (HBM / L2), not by arithmetic.
-        fused = int(ks["fast_levels"]) == 254
-        F2 = 8192 if fused else 16384
-        Pq = int(ks["partitions"])
-        blk = ks["blocks"] // max(ks["launches"], 1)
-        nchunk = -(-blk // (F2 - Pq + 1))
-        if fused:
-            # one kernel, both inputs' spectra side by side in LDS: the window once (16 B per slot), 4 paths of
-            # second-level spectra per chunk, the partition sums written
-            own_bytes = 256 * (16 * (blk + nchunk * (Pq - 1)) + 4 * 8 * F2 * nchunk + 16 * blk)
-        else:
-            # windows of 2 inputs + their transforms parked once and read by both channel passes + 4 paths of
-            # second-level spectra + the partition sums written
-            own_bytes = 256 * (2 * 8 * (blk + nchunk * (Pq - 1)) + (2 + 4) * 8 * F2 * nchunk + 4 * 8 * F2 * nchunk + 16 * blk)
-        own_gbs = own_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-        common["kernel"] = "k_g2_mac" if fused else "k_f2_fwd + k_f2_prod"
-        roofline = dict({"bound": "hbm", "achieved": round(own_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(own_gbs / HBM_PEAK_GBS, 4)}, **common)
-        roofline["algorithmic_bytes_per_launch"] = own_bytes
-        roofline["replaces"] = {"kernel": "partition x bin MAC (direct form)", "tflops_equivalent": round(achieved_tf, 2),
-                                "frac_of_fp32_peak": round(achieved_tf / FP32_PEAK_TFLOPS, 4), "hbm_equivalent": hbm_equiv}
-        roofline["note"] = ("The batch's partition sums are computed by a second-level transform along the block axis instead of "
-                            "the partition x bin MAC: per bin one circular convolution per chunk of blocks (8192 points with both "
-                            "inputs' spectra side by side in 133 KB of LDS, k_g2_mac; 16384 points through a stash for long IRs "
-                            "and per-slot gains, k_f2_fwd + k_f2_prod) against the IRs' transformed partition sequences. "
-                            "achieved = the kernel's own algorithmic bytes (delay-line window, second-level spectra of 4 paths "
-                            "per chunk, partition sums written; the split form also its stash) / kernel time (HIP events on the launch stream); `traffic` "
-                            "(HBM side, PMC counters) is lower because the chunks of a bin run together on one XCD and share its spectra and "
-                            "the overlap of their windows in that L2; `replaces` prices the same launch as "
-                            "the direct-form MAC it stands for (SURVEY 8(d) accounting). MCCONV_FFT2=0 runs the MAC kernel "
-                            "(fast-FIR form), MCCONV_FFA_LEVELS=0 its direct form.")
-    elif ks["resident"]:
-        # the batch kernel keeps the IR on chip across the blocks of a launch (HBM traffic << algorithmic bytes):
-        # its binding resource is fp32 FMA issue.  The f32 MFMA peak of gfx950 equals the vector rate (157.3 TF).
-        roofline = dict({"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4)}, **common)
+    if not sharded:
+        r = run_single()
+        T, dt, ks = r["T"], r["dt"], r["ks"]
+        rtf = a.steps * T * BLOCK / FS / dt
+        alg_bytes = r["alg_bytes"]
+        kern_s = ks["total_ms"] * 1e-3
+        kern_avg_ms = ks["total_ms"] / max(ks["launches"], 1)
+        blk = (ks["blocks"] // max(ks["launches"], 1)) if ks["launches"] else T
+        flops_per_block = 8.0 * 4 * ks["partitions"] * 256  # complex MAC = 8 flop, 4 paths
+        achieved_tf = flops_per_block * ks["blocks"] / kern_s / 1e12 if kern_s > 0 else 0.0
+        survey_gbs = alg_bytes * ks["blocks"] / kern_s / 1e9 if kern_s > 0 else 0.0
+        survey = {"achieved": round(survey_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(survey_gbs / HBM_PEAK_GBS, 4),
+                  "algorithmic_bytes_per_block": alg_bytes,
+                  "note": "SURVEY 8(d) accounting of the partition x bin MAC (every block re-reads 4 IR paths + 2 delay-line "
+                          "inputs) x blocks / kernel time. A frac far above 1 says what it looks like: the timed kernel does NOT do "
+                          "that work - it replaces the MAC by a transform along the block axis; the literal MAC is k_mac_stream "
+                          "(latency_mode) and MCCONV_FFT2=0"}
+        common = {"kernel_avg_ms": round(kern_avg_ms, 5), "kernel_launches": ks["launches"], "blocks_per_launch": blk,
+                  "timed_with": "HIP events on the launch stream around the kernel, inside the timed steps"}
         lv = int(ks.get("fast_levels", 0))
-        executed_tf = achieved_tf * (0.75 ** lv)
-        roofline["executed"] = {"fast_fir_levels": lv, "multiply_add_fraction": round(0.75 ** lv, 4),
-                                "tflops": round(executed_tf, 2), "frac": round(executed_tf / FP32_PEAK_TFLOPS, 4)}
-        roofline["hbm_equivalent"] = hbm_equiv
-        roofline["note"] = ("fp32 complex MAC on the vector ALU (v_pk_fma_f32; no MFMA instruction is used - the f32 MFMA rate "
-                            "of gfx950 equals the vector rate, so the peak is the same 157.3 TFLOP/s). achieved = ALGORITHMIC flops "
-                            "of the partition x bin MAC, 8 flop x 4 paths x partitions x 256 bins x blocks / MAC kernel time (HIP "
-                            "events on the launch stream). The kernel runs the convolution along the block axis in fast-FIR form "
-                            "(polyphase components, `executed.fast_fir_levels` nested levels): it issues (3/4)^levels of those "
-                            "multiply-adds, so `achieved` can exceed the peak; `executed` is what the ALUs do. "
-                            "traffic = HBM bytes per launch from FETCH_SIZE/WRITE_SIZE (profiles/).")
-    else:
-        roofline = dict({"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4)}, **common)
-        roofline["algorithmic_bytes_per_block"] = alg_bytes
-        roofline["fp32_tflops"] = round(achieved_tf, 2)
-        roofline["note"] = ("streaming MAC: every block re-reads IR spectra and delay line; achieved = algorithmic bytes x blocks / "
-                            "kernel time. With many blocks per launch the 21 MB working set is served from L2/MALL, so achieved can "
-                            "exceed the HBM peak; one block per launch (latency_mode) is the HBM/MALL-bound case.")
-    if rank == 0:
-        line = {
-            "metric": "real-time factor (frames/s / 44.1k), stereo block=256, 10 s IR",
+        if ks["resident"] and lv in (254, 255):
+            fused = lv == 254
+            cb = second_level_bytes(blk, int(ks["partitions"]), fused)
+            gbs = cb["total"] / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+            tr = labelled_profile("r2_hbm_traffic.json", "k_g2_mac" if fused else "k_f2")
+            traffic = None
+            if tr and int(tr["data"].get("blocks_per_launch", -1)) == int(blk):
+                traffic = tr["data"].get("hbm_bytes_per_launch")
+            roofline = dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                             "kernel": "k_g2_mac" if fused else "k_f2_fwd + k_f2_prod"}, **common)
+            roofline["algorithmic_bytes_per_launch"] = cb["total"]
+            roofline["algorithmic_bytes"] = cb
+            if tr:
+                roofline["traffic_source"] = {k: tr[k] for k in ("from", "commit", "note")}
+            bind = labelled_profile("r2_g2_counters.json")
+            if bind:
+                roofline["binding_resource"] = bind
+            roofline["survey_8d_accounting"] = survey
+            roofline["direct_form_equivalent_tflops"] = round(achieved_tf, 2)
+            roofline["note"] = ("achieved = COMPULSORY bytes of the launch (every delay-line slot of the window once, the four "
+                                "paths' second-level spectra once, the partition sums written" + ("" if fused else ", the stash written and read once")
+                                + ") / kernel time. The kernel is a second-level transform along the block axis (per bin one circular "
+                                "convolution per chunk of blocks), not the partition x bin MAC of SURVEY 8(d); survey_8d_accounting "
+                                "prices it that way for reference.")
+        elif ks["resident"]:
+            roofline = dict({"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_mac_resident"}, **common)
+            executed_tf = achieved_tf * (0.75 ** lv)
+            roofline["executed"] = {"fast_fir_levels": lv, "multiply_add_fraction": round(0.75 ** lv, 4),
+                                    "tflops": round(executed_tf, 2), "frac": round(executed_tf / FP32_PEAK_TFLOPS, 4)}
+            roofline["survey_8d_accounting"] = survey
+            roofline["note"] = ("fp32 complex MAC on the vector ALU (v_pk_fma_f32; the f32 MFMA rate of gfx950 equals the vector rate). "
+                                "achieved = ALGORITHMIC flops of the partition x bin MAC / kernel time; the fast-FIR form issues "
+                                "(3/4)^levels of them (`executed`).")
+        else:
+            roofline = dict({"bound": "hbm", "achieved": round(survey_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(survey_gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_mac_stream"}, **common)
+            roofline["algorithmic_bytes_per_block"] = alg_bytes
+            roofline["note"] = ("streaming MAC: every block re-reads IR spectra and delay line; achieved = SURVEY 8(d) bytes x blocks / "
+                                "kernel time. With many blocks per launch the working set is served from L2 / Infinity Cache, so "
+                                "achieved can exceed the HBM peak.")
+        line.update({
             "value": round(rtf, 2),
-            "unit": "x realtime",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak" if (by_blocks or (not sharded and a.shard == "blocks")) else "strong",
-            "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "f16 storage, f32 accumulate",
-            "data": "synthetic",
-            "config": {
-                "workload": f"stereo 44.1 kHz, 256-frame blocks, {a.taps}-tap IR ({P} partitions, N_ref {a.fft_size}), "
-                            f"2x2 path matrix, {T} blocks per step, "
-                            + ("IR spectra re-read for every block (streaming MAC)" if a.mode == "stream" else
-                               "IR resident across the batch (sum over partitions: " + str(roofline.get("kernel")) + ")"),
-                "blocks_per_step": T,
-                "partitions": P,
-                "paths": 4,
-                "mode": a.mode,
-                "parallelism": "single GPU" if not sharded else
-                (f"output blocks of every batch sliced over {world} GPU(s) ({count} blocks each, every GPU holds the whole IR "
-                 f"and transforms the whole input); no data-path collective, "
-                 + (f"slices gathered to rank 0 ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})" if a.exchange == "gather"
-                    else "slices left on their ranks") if by_blocks else
-                 f"IR partitions sharded over {world} GPU(s) + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} {a.collective} of partial wet blocks")
-                + ("" if a.no_overlap else ", overlapped with the next batch"),
-                "shard": (a.shard if sharded else None),
-            },
+            "scaling": "weak",
+            "config": {"workload": workload + f", {T} blocks per step, "
+                                   + ("IR spectra re-read for every block (streaming MAC)" if a.mode == "stream" else
+                                      "sum over partitions by " + str(roofline.get("kernel"))),
+                       "blocks_per_step": T, "partitions": P, "paths": 4 * npairs, "mode": a.mode, "parallelism": "single GPU"},
             "roofline": roofline,
-            "cpu_baseline": cpu,
-            "latency_mode": latency,
-        }
-        if sharded_check is not None:
-            line["sharded_check"] = sharded_check
+            "parity": r.get("parity"),
+            "cpu_baseline": r.get("cpu_baseline"),
+            "host_io": r.get("host_io"),
+            "latency_mode": r.get("latency_mode"),
+            "prewarm": r["prewarm"],
+        })
+    else:
+        rb = run_blocks() if a.layouts in ("both", "blocks") else None
+        rp = run_partitions() if a.layouts in ("both", "partitions") else None
+        main_r = rb if rb is not None else rp
+        by_blocks = rb is not None
+        ex = "RCCL" if a.backend == "nccl" else "gloo (rehearsal)"
+        par_blocks = (f"dp{world}: output blocks of every batch sliced over {world} GPU(s) ({rb['count']} blocks each; every GPU holds "
+                      f"the whole IR set and transforms the input its windows reach); no data-path collective, "
+                      + (f"slices gathered to rank 0 ({ex})" if a.exchange == "gather" else "slices left on their ranks")) if rb else None
+        par_parts = (f"IR partitions sharded over {world} GPU(s) ({rp['partitions_per_rank']} of {P} per rank) + {ex} {a.collective} of the "
+                     f"partial wet blocks ({rp['reduce_bytes_per_step'] / 1e6:.0f} MB per step), overlapped with the next batch") if rp else None
+        why = ("`value` is the block-sliced layout: given the input, the output blocks of a batch are independent units, so they "
+               "shard with no exchange step at all; the north-star layout (partition shards + RCCL sum) is measured in the same "
+               "run under north_star_layout. It cannot scale batch throughput on this engine: the sum over partitions is a "
+               "transform along the block axis whose cost does not depend on the number of partitions, so every rank still does "
+               "the whole forward / second-level / inverse work and the step only gains a 66 MB reduce; it is the layout for IR "
+               "sets that do not fit one GPU.")
+        line.update({
+            "value": round(main_r["rtf"], 2),
+            "ms_per_step": round(main_r["dt"] / a.steps * 1e3, 4),
+            "scaling": "weak" if by_blocks else "strong",
+            "config": {"workload": workload + f", {main_r['T']} blocks per step", "blocks_per_step": main_r["T"], "partitions": P,
+                       "paths": 4 * npairs, "mode": a.mode,
+                       "parallelism": (par_blocks + ". " + why) if by_blocks else par_parts},
+        })
+        if rb is not None and "sharded_check" in rb:
+            line["sharded_check"] = rb["sharded_check"]
+        if rp is not None:
+            ns = {"value": round(rp["rtf"], 2), "unit": "x realtime", "ms_per_step": round(rp["dt"] / a.steps * 1e3, 4),
+                  "scaling": "strong", "blocks_per_step": rp["T"], "parallelism": par_parts,
+                  "sum_over_partitions": rp["sum_over_partitions"],
+                  "reduce_GBps": round(rp["reduce_bytes_per_step"] * a.steps / rp["dt"] / 1e9, 2)}
+            if "sharded_check" in rp:
+                ns["sharded_check"] = rp["sharded_check"]
+            if by_blocks:
+                line["north_star_layout"] = ns
+            else:
+                line["sharded_check"] = rp.get("sharded_check")
+    if rank == 0:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    eng.close()
     if sharded:
         dist.destroy_process_group()
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "mc_process", "mc_process_batch", "mc_process_batch_device", "mc_partial_batch_device",
     "mc_finish_batch_device", "mc_process_batch_slice_device", "mc_sync", "mc_fence", "mc_fence_older", "mc_set_stream", "mc_get_stream", "mc_avg_runtime_ms",
     "mc_enable_kernel_timing", "mc_get_kernel_stats", "mc_algorithmic_bytes_per_block", "mc_blocks_processed", "mc_preferred_batch",
-    "mc_debug_read",
+    "mc_debug_read", "mc_host_alloc", "mc_host_free",
 ]
 
 
@@ -136,6 +136,10 @@ def load():
     L.mc_preferred_batch.argtypes = [vp, u64]
     L.mc_preferred_batch.restype = u64
     L.mc_debug_read.argtypes = [vp, C.c_int, u64, vp, u64, u64, C.POINTER(u64)]
+    L.mc_host_alloc.argtypes = [C.c_size_t]
+    L.mc_host_alloc.restype = vp
+    L.mc_host_free.argtypes = [vp]
+    L.mc_host_free.restype = None
     _lib = L
     return L
 

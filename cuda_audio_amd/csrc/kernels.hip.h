@@ -2436,6 +2436,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__
 
 // grid = 256 bins x chunks, block = 1024 (two halves: input 1 / input 2, later Y_L / Y_R).
 // chunk_t + taps - 1 <= G2_N.
+// Bounds of every global access (host checks: nitems = 256 * ceil(T / chunk_t), T <= ycap, ring a power of two,
+// grid <= nitems; any grid >= 1 is correct, the loop strides over the items):
+//   items    the loop runs item = blockIdx.x (< gridDim.x <= nitems), + gridDim.x while < nitems; the look-ahead for
+//            item + gridDim.x is issued only under the same `< nitems` test, so window_row never sees an item
+//            >= nitems.  item -> xq = item >> 3 < 32 nch, bin = (xq / nch) * 8 + (item & 7) < 256, chunk = xq % nch.
+//   window   fdl[bin * ring + ((sb + n) & (ring - 1))]: the mask keeps the slot in [0, ring) for any sb (negative
+//            at the start of the stream, wrapping later), bin < 256: inside fdl's 256 * ring entries.  Rows with
+//            n >= L are not loaded.
+//   spectra  float4 index j = tid + 1024 r < 4096 into a row of G2_N float2 = 4096 float4; rows (c * 257 + row),
+//            c < 2, row <= 256: inside the IR's 2 * 257 * G2_N entries.  j passes through an empty asm only to stop
+//            the compiler hoisting the address arithmetic above the transforms; its value is unchanged.
+//   sums     Yc[bin * ycap + t_c0 + t], t < nout = min(chunk_t, T - t_c0): t_c0 + t < T <= ycap.
+// LDS: G2_P(n) <= G2_P(8191) = 8446 < G2_LDS; the mirrored positions of bin 0 are permutations of [0, G2_N).
 __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
                                                        int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
     __shared__ float2 s[2][G2_LDS];

@@ -115,7 +115,13 @@ struct mc_engine {
     BlockParams* d_ptab = nullptr;
     float2* d_tw = nullptr;
     float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // in1, in2, outL, outR staging for host-pointer calls
-    int Thost = 0;                                          // longest batch through host buffers (staging capacity)
+    int Thost = 0;                                          // blocks per chunk of a host-buffer batch staged through h_io
+    // host-buffer batches whose buffers are pinned (mc_host_alloc, hipHostMalloc, hipHostRegister): chunks of Tdev blocks,
+    // H2D / compute / D2H on three streams, two chunks in flight; device staging allocated on first use
+    float* d_pio[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    int Tdev = 0;
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Thost * 256
     float* hd_io = nullptr;                                 // device-side address of h_io (mapped, zero-copy)
     unsigned* h_flag = nullptr;                             // completion word of the single-period path (mapped)
@@ -175,6 +181,7 @@ struct mc_engine {
     hipEvent_t ev_tail = nullptr;
     bool fft2 = true;     // long batches: second-level transform along the block axis instead of the MAC
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
+    bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
     int g2_grid = 256;       // workgroups of k_g2_mac: one per CU (set at create), each loops over its (bin, chunk) items; MCCONV_G2_GRID
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
@@ -294,7 +301,9 @@ int ensure_fft2(mc_engine* e, const IrEntry* irc) {
     IrEntry& ir = *const_cast<IrEntry*>(irc);
     if (ir.h2_valid) return MC_OK;
     if (!ir.d_H2) HIP_TRY(hipMalloc(&ir.d_H2, sizeof(float2) * (size_t)2 * 257 * F2_N));
-    hipLaunchKernelGGL(k_fft2_ir, dim3(257, 2), dim3(F2_THREADS), 0, e->stream, ir.d_H, e->Pstride, std::min(ir.P, F2_N), ir.d_H2);
+    // a partition shard transforms its own run of the partition sequence, H[pb .. pe)
+    const int pb = std::min<int>((int)e->cfg.part_begin, ir.P), pe = e->cfg.part_end ? std::min<int>((int)e->cfg.part_end, ir.P) : ir.P;
+    hipLaunchKernelGGL(k_fft2_ir, dim3(257, 2), dim3(F2_THREADS), 0, e->stream, ir.d_H + pb, e->Pstride, std::min(std::max(pe - pb, 0), F2_N), ir.d_H2);
     HIP_TRY(hipGetLastError());
     ir.h2_valid = true;
     return MC_OK;
@@ -304,7 +313,8 @@ int ensure_g2(mc_engine* e, const IrEntry* irc) {
     IrEntry& ir = *const_cast<IrEntry*>(irc);
     if (ir.g2_valid) return MC_OK;
     if (!ir.d_G2) HIP_TRY(hipMalloc(&ir.d_G2, sizeof(float2) * (size_t)2 * 257 * G2_N));
-    hipLaunchKernelGGL(k_g2_ir, dim3(257), dim3(G2_THREADS), 0, e->stream, ir.d_H, e->Pstride, std::min(ir.P, G2_N), ir.d_G2);
+    const int pb = std::min<int>((int)e->cfg.part_begin, ir.P), pe = e->cfg.part_end ? std::min<int>((int)e->cfg.part_end, ir.P) : ir.P;
+    hipLaunchKernelGGL(k_g2_ir, dim3(257), dim3(G2_THREADS), 0, e->stream, ir.d_H + pb, e->Pstride, std::min(std::max(pe - pb, 0), G2_N), ir.d_G2);
     HIP_TRY(hipGetLastError());
     ir.g2_valid = true;
     return MC_OK;
@@ -706,15 +716,30 @@ void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, boo
     if (mo.tail_n > 0) inv(mo.tail_ysrc, mo.tail_sk, mo.tail_stt, mo.tail_nsum, (int64_t)1, mo.tail_n, b0 + (uint64_t)mo.main_n);
 }
 
+// Taps of the convolution along the block axis that this engine sums: the longest sounding IR's partitions, or the
+// engine's shard of them - a shard [pb, pe) is a (pe - pb)-tap convolution whose window starts pb slots earlier.
+int block_axis_taps(const mc_engine* e, const ActiveVoice* act, int nact, int* pb_out) {
+    int taps = 0, pb0 = (int)e->cfg.part_begin;
+    for (int a = 0; a < nact; a++) {
+        int pb, pe;
+        partition_range(e, act[a].p_end, &pb, &pe);
+        taps = std::max(taps, pe - pb);
+    }
+    if (pb_out) *pb_out = pb0;
+    return taps;
+}
+
 // Will launch_mac_batch take the second-level transform for this batch?
 bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T) {
     (void)per_slot_gains;  // both gain layouts are handled (uniform: 2 sequences per bin; per slot: 4 per voice)
-    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || e->cfg.part_begin || e->cfg.part_end || nact <= 0 ||
+    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || nact <= 0 ||
         T < 768)  // measured crossover with the direct MAC: ~600 blocks (0.095 ms whatever the batch length)
         return false;
-    int pmax = 0;
-    for (int a = 0; a < nact; a++) pmax = std::max(pmax, act[a].p_end);
-    return pmax >= 256 && pmax <= F2_N / 2;
+    const int taps = block_axis_taps(e, act, nact, nullptr);
+    if (e->cfg.part_begin || e->cfg.part_end)
+        // a shard's direct MAC costs ~0.076 ns per block and partition, the transform ~0.1 ms per launch of <= 6465 blocks
+        return taps >= 16 && taps <= F2_N / 2 && (int64_t)T * taps >= 1300000;
+    return taps >= 256 && taps <= F2_N / 2;
 }
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
@@ -739,8 +764,9 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     // convolution per (bin, chunk of blocks) with a second-level transform of length F2_N (k_f2_fwd, k_f2_prod); the IRs'
     // partition sequences are transformed once (k_fft2_ir).  O(log) instead of O(P) work per output block.
     if (fft2_applies(e, act, nact, per_slot_gains, T)) {
-        int pmax = 0;
-        for (int a = 0; a < nact; a++) pmax = std::max(pmax, act[a].p_end);
+        int pb0 = 0;
+        const int pmax = block_axis_taps(e, act, nact, &pb0);  // taps of this engine's (shard of the) convolution
+        slot0 = (slot0 - pb0) & (e->ring - 1);                  // a shard's window starts pb slots earlier
         {
             Fft2Voices vv;
             std::memset(&vv, 0, sizeof(vv));
@@ -768,6 +794,16 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 }
                 const int chunk_t = G2_N - pmax + 1;
                 const int nch = (T + chunk_t - 1) / chunk_t;
+                if (e->debug_addr) {
+                    // every address the kernel forms lies in one of these ranges (see the bounds argument at k_g2_mac)
+                    e->debug_addr = false;
+                    fprintf(stderr, "mcconv k_g2_mac: T %d chunk_t %d taps %d items %d grid %d\n  fdl  [%p, %p)\n  Yc   [%p, %p) (written: %d of %d entries per bin)\n",
+                            T, chunk_t, pmax, MC_NB * nch, std::min(MC_NB * nch, e->g2_grid), (void*)e->d_fdl, (void*)(e->d_fdl + (size_t)MC_NB * e->ring),
+                            (void*)e->d_Yc, (void*)(e->d_Yc + (size_t)MC_NB * e->Tcap), T, e->Tcap);
+                    for (int a = 0; a < nact; a++)
+                        fprintf(stderr, "  G2[%d] in1 [%p, %p) in2 [%p, %p)\n", a, (void*)vv.h0[a], (void*)(vv.h0[a] + (size_t)2 * 257 * G2_N),
+                                (void*)vv.h1[a], (void*)(vv.h1[a] + (size_t)2 * 257 * G2_N));
+                }
                 hipLaunchKernelGGL(k_g2_mac, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0,
                                    T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
                 mo->ysrc = e->d_Yc;
@@ -1366,26 +1402,95 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     return MC_OK;
 }
 
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime: not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// Host-buffer batch through the engine's own pinned staging buffer (pageable caller memory, as JACK's buffers are in
+// the reference, conv.cu:321-328, 431-437): chunks of Thost blocks, each copied in, processed and copied out in turn.
+int process_host_staged(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
+    const size_t cap = (size_t)e->Thost * MC_B;
+    for (int o = 0; o < T; o += e->Thost) {
+        const int n = std::min(e->Thost, T - o);
+        const size_t bytes = (size_t)n * MC_B * sizeof(float), off = (size_t)o * MC_B;
+        std::memcpy(e->h_io + 0 * cap, in1 + off, bytes);
+        std::memcpy(e->h_io + 1 * cap, in2 + off, bytes);
+        HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_io[1], e->h_io + 1 * cap, bytes, hipMemcpyHostToDevice, e->stream));
+        int rc = run_front(e, e->d_io[0], e->d_io[1], n, nullptr, 0, n);
+        if (rc) return rc;
+        rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], n);
+        if (!rc) rc = fence_post(e);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->h_io + 2 * cap, e->d_io[2], bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->h_io + 3 * cap, e->d_io[3], bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        std::memcpy(outL + off, e->h_io + 2 * cap, bytes);
+        std::memcpy(outR + off, e->h_io + 3 * cap, bytes);
+    }
+    return MC_OK;
+}
+
+// Host-buffer batch with pinned caller memory: the DMA engines read and write the caller's buffers directly.  Chunks
+// of Tdev blocks; chunk k's copy-in (H2D stream), chunk k - 1's kernels (engine stream) and chunk k - 2's copy-out
+// (D2H stream) run together.  Returns when the last output byte is in outL / outR.
+int process_host_pinned(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
+    if (!e->Tdev) {
+        // one chunk of the second-level transform where it applies: short enough that copy-in, kernels and copy-out of
+        // neighbouring chunks overlap well (the copies, not the kernels, set the pace)
+        int tdev = (int)std::min<uint64_t>(mc_preferred_batch(e, std::min(e->Tmax, 8192)), (uint64_t)e->Tmax);
+        tdev = std::max(tdev / e->pm * e->pm, e->pm);
+        for (int b = 0; b < 2; b++)
+            for (int i = 0; i < 4; i++) HIP_TRY(hipMalloc(&e->d_pio[b][i], sizeof(float) * (size_t)tdev * MC_B));
+        HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_comp[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_d2h[b], hipEventDisableTiming));
+        }
+        e->Tdev = tdev;
+    }
+    int k = 0;
+    for (int o = 0; o < T; o += e->Tdev, k++) {
+        const int n = std::min(e->Tdev, T - o), b = k & 1;
+        const size_t bytes = (size_t)n * MC_B * sizeof(float), off = (size_t)o * MC_B;
+        float* const* d = e->d_pio[b];
+        // the staging pair is free once chunk k - 2 has been computed (inputs) and copied out (outputs)
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->h2d_stream, e->ev_comp[b], 0));
+        HIP_TRY(hipMemcpyAsync(d[0], in1 + off, bytes, hipMemcpyHostToDevice, e->h2d_stream));
+        HIP_TRY(hipMemcpyAsync(d[1], in2 + off, bytes, hipMemcpyHostToDevice, e->h2d_stream));
+        HIP_TRY(hipEventRecord(e->ev_h2d[b], e->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_d2h[b], 0));
+        int rc = run_front(e, d[0], d[1], n, nullptr, 0, n);
+        if (rc) return rc;
+        rc = run_back(e, d[0], d[1], nullptr, d[2], d[3], n);
+        if (!rc) rc = fence_post(e);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->ev_comp[b], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->d2h_stream, e->ev_comp[b], 0));
+        HIP_TRY(hipMemcpyAsync(outL + off, d[2], bytes, hipMemcpyDeviceToHost, e->d2h_stream));
+        HIP_TRY(hipMemcpyAsync(outR + off, d[3], bytes, hipMemcpyDeviceToHost, e->d2h_stream));
+        HIP_TRY(hipEventRecord(e->ev_d2h[b], e->d2h_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->d2h_stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return MC_OK;
+}
+
 int process_host(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
-    if (T <= 0 || T > e->Thost) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d] (host-buffer batches)", T, e->Thost);
-    const size_t n = (size_t)T * MC_B, bytes = n * sizeof(float);
-    const size_t cap = (size_t)e->Thost * MC_B;
-    std::memcpy(e->h_io + 0 * cap, in1, bytes);
-    std::memcpy(e->h_io + 1 * cap, in2, bytes);
-    HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_io[1], e->h_io + 1 * cap, bytes, hipMemcpyHostToDevice, e->stream));
-    int rc = run_front(e, e->d_io[0], e->d_io[1], T, nullptr, 0, T);
-    if (rc) return rc;
-    rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], T);
-    if (!rc) rc = fence_post(e);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_io + 2 * cap, e->d_io[2], bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->h_io + 3 * cap, e->d_io[3], bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    std::memcpy(outL, e->h_io + 2 * cap, bytes);
-    std::memcpy(outR, e->h_io + 3 * cap, bytes);
-    return MC_OK;
+    if (T <= 0) return fail(MC_ERR_ARG, "nblocks %d < 1", T);
+    if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
+    if (is_pinned_host(in1) && is_pinned_host(in2) && is_pinned_host(outL) && is_pinned_host(outR))
+        return process_host_pinned(e, in1, in2, outL, outR, T);
+    return process_host_staged(e, in1, in2, outL, outR, T);
 }
 
 // One JACK period of 512 / 1024 frames (pm = 2 / 4 blocks): the batch pipeline with zero-copy I/O - k_fwd reads the
@@ -1668,7 +1773,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_gring, sizeof(float4) * (size_t)MC_MAXV * e->rc));
     ENG_TRY(hipMalloc(&e->d_ptab, sizeof(BlockParams) * (size_t)e->Tmax * kPipe));
     ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
-    e->Thost = std::min(e->Tmax, 16384);  // host-buffer calls stage through pinned memory: bounded
+    e->Thost = std::min(e->Tmax, 16384);  // host-buffer calls with pageable buffers stage through pinned memory in chunks of this
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Thost * MC_B));
     ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
@@ -1690,7 +1795,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) e->g2_grid = cus & ~7;
     }
-    if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(8, std::atoi(gg) & ~7);
+    // (any grid >= 1 is correct: a workgroup strides over the items; multiples of 8 keep a bin's chunks on one XCD)
+    if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
+    if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
@@ -1759,6 +1866,14 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_ptab);
     (void)hipFree(e->d_tw);
     for (int i = 0; i < 4; i++) (void)hipFree(e->d_io[i]);
+    for (int b = 0; b < 2; b++) {
+        for (int i = 0; i < 4; i++) (void)hipFree(e->d_pio[b][i]);
+        if (e->ev_h2d[b]) (void)hipEventDestroy(e->ev_h2d[b]);
+        if (e->ev_comp[b]) (void)hipEventDestroy(e->ev_comp[b]);
+        if (e->ev_d2h[b]) (void)hipEventDestroy(e->ev_d2h[b]);
+    }
+    if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
+    if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
     if (e->h_io) (void)hipHostFree(e->h_io);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     for (int i = 0; i < kStageBufs; i++) {
@@ -1933,6 +2048,20 @@ int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, fl
     return MC_OK;
 }
 
+void* mc_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(MC_ERR_NOMEM, "mc_host_alloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void mc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int mc_process_batch(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, uint64_t nblocks) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
@@ -2073,8 +2202,14 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
     int pmax = 0;
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_H) pmax = std::max(pmax, round_up(e->irs[i].P, 16));
+    const bool shard = e->cfg.part_begin || e->cfg.part_end;
+    if (shard) {  // taps of the shard's own run of partitions
+        int pb, pe;
+        partition_range(e, pmax, &pb, &pe);
+        pmax = pe - pb;
+    }
     uint64_t chunk = 0;
-    if (e->fft2 && !e->half && !e->cfg.part_begin && !e->cfg.part_end && pmax >= 256) {
+    if (e->fft2 && !e->half && (shard ? pmax >= 16 : pmax >= 256)) {
         if (e->fft2_fused && pmax <= 2560) chunk = (uint64_t)(G2_N - pmax + 1);
         else if (pmax <= F2_N / 2) chunk = (uint64_t)(F2_N - pmax + 1);
     }

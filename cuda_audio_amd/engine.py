@@ -9,6 +9,7 @@ returns the two playback buffers.  All arithmetic runs in libmcconv.so (HIP);
 there is no CPU path here.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -149,21 +150,29 @@ class Convolution:
         return self._L.mc_avg_runtime_ms(self._h)
 
     # -- throughput surface -----------------------------------------------------
-    def process(self, in1, in2):
-        """Consecutive blocks from host arrays (length multiple of 256), batched
-        max_batch blocks per call; returns float32 [2, n]."""
+    def process(self, in1, in2, out=None):
+        """Consecutive blocks from host arrays (length a multiple of 256) in ONE mc_process_batch call; returns
+        float32 [2, n].  The engine cuts long runs into chunks itself (16384 blocks through its pinned staging
+        buffer for pageable arrays; its preferred batch, three streams, for pinned ones - `pinned_array`)."""
         in1, in2 = _f32(in1), _f32(in2)
         n = in1.shape[0]
         if n % MC_BLOCK or in2.shape[0] != n:
             raise ValueError("inputs must have equal length, a multiple of 256")
-        out = np.empty((2, n), np.float32)
-        step = min(self.max_batch, 16384) * MC_BLOCK  # host-buffer batches stage through pinned memory: <= 16384 blocks
-        for o in range(0, n, step):
-            m = min(step, n - o)
-            a, b = in1[o : o + m], in2[o : o + m]
-            check(self._L.mc_process_batch(self._h, _fp(a), _fp(b), _fp(out[0, o : o + m]), _fp(out[1, o : o + m]),
-                                           m // MC_BLOCK))
+        if out is None:
+            out = np.empty((2, n), np.float32)
+        check(self._L.mc_process_batch(self._h, _fp(in1), _fp(in2), _fp(out[0]), _fp(out[1]), n // MC_BLOCK))
         return out
+
+    def pinned_array(self, shape):
+        """float32 array in pinned host memory (mc_host_alloc): buffers of this kind let mc_process_batch overlap
+        copy-in, kernels and copy-out.  Freed with the array (keeps a reference to its allocation)."""
+        n = int(np.prod(shape))
+        p = self._L.mc_host_alloc(n * 4)
+        if not p:
+            raise MemoryError("mc_host_alloc failed")
+        buf = (C.c_float * n).from_address(p)
+        weakref.finalize(buf, self._L.mc_host_free, p)  # every view of the array keeps `buf` alive
+        return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
     def process_device(self, d_in1, d_in2, d_outL, d_outR, nblocks):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous."""

@@ -52,7 +52,7 @@ void Convolution::pushParams() {
         v.select = cc[i].value.select;
         v.predelay = cc[i].value.predelay;
         v.speed = cc[i].value.speed;
-        v.vsteps = cc[i].value.vsteps;
+        v.vsteps = _pushedVsteps[i] = cc[i].value.vsteps;
         v.dry = cc[i].value.dry;
         v.wet = cc[i].value.wet;
         v.panDry = cc[i].value.panDry;
@@ -66,7 +66,10 @@ void Convolution::pullVsteps() {
     for (int i = 0; i < 2; i++) {
         mc_cc_value v;
         check(mc_get_params(_engine, i, &v), "mc_get_params");
-        cc[i].value.vsteps = v.vsteps;  // counts down once per block (conv.cu:345,353)
+        // counts down once per block (conv.cu:345,353).  A select that arrived from the MIDI thread while the engine
+        // was processing has reset vsteps to speed (conv.cu:261): like the reference's in-place decrement, the
+        // write-back must not undo it - only the value that was handed to the engine is replaced
+        if (cc[i].value.vsteps == _pushedVsteps[i]) cc[i].value.vsteps = v.vsteps;
     }
 }
 

@@ -70,6 +70,7 @@ private:
     size_t _fftSize;
     size_t _nirs = 0;
     size_t _period = 256;
+    size_t _pushedVsteps[2] = {0, 0};  // cc[i].value.vsteps as last handed to the engine (see pullVsteps)
     void pushParams();
     void pullVsteps();
 };

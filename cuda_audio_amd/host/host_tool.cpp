@@ -4,6 +4,7 @@
 //   wavwrite <in.f32> <out.wav> <bits> encode interleaved float32 frames with WavFile::write
 //   settings <file> <key>...          print "key=value" for each printf-free key
 //   midi <hexbytes>                   feed bytes to a RawMidi::Device, print dispatched messages
+//   operators                         every operator of operators.h on fixed operands, one result per line
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include "log.h"
 #include "midi.h"
 #include "settings.h"
+#include "operators.h"
 #include "wav.h"
 
 struct Printer : RawMidi::MessageHandler {
@@ -76,6 +78,33 @@ int main(int argc, char** argv) {
             bytes.push_back((uint8_t)strtoul(t, nullptr, 16));
         }
         d.feed(bytes.data(), bytes.size());
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "operators")) {
+        // the reference's kernels index with dim3 arithmetic (conv.cu:18-19 and every other kernel) and do their
+        // float2 arithmetic with these operators (conv.cu:25-30, 58-70, 95-98, 134-137)
+        const host_dim3 blockDim{256, 1, 1}, gridDim{64, 2, 1};
+        const host_uint3 blockIdx{5, 1, 0}, threadIdx{17, 0, 0};
+        const host_dim3 offset = blockDim * blockIdx + threadIdx, stride = blockDim * gridDim;
+        printf("offset=%u,%u,%u stride=%u,%u,%u\n", offset.x, offset.y, offset.z, stride.x, stride.y, stride.z);
+        const wav_float2 a{1.5f, -2.0f}, b{0.25f, 4.0f};
+        wav_float2 r = a + b;
+        printf("add=%g,%g\n", r.x, r.y);
+        r = a - b;
+        printf("sub=%g,%g\n", r.x, r.y);
+        r = a * 2.0f;
+        printf("mul=%g,%g\n", r.x, r.y);
+        r = 2.0f * a;
+        printf("lmul=%g,%g\n", r.x, r.y);
+        r = a / 4.0f;
+        printf("div=%g,%g\n", r.x, r.y);
+        r = a;
+        r += b;
+        printf("addeq=%g,%g\n", r.x, r.y);
+        r += 0.5f;
+        printf("addeqs=%g,%g\n", r.x, r.y);
+        r = clamp(wav_float2{3.0f, -3.0f}, -1.0f, 1.0f);
+        printf("clamp=%g,%g\n", r.x, r.y);
         return 0;
     }
     fprintf(stderr, "unknown command\n");

@@ -12,12 +12,18 @@
 struct host_dim3 {
     unsigned x = 1, y = 1, z = 1;
 };
-inline host_dim3 operator*(host_dim3 a, host_dim3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-inline host_dim3 operator+(host_dim3 a, host_dim3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+struct host_uint3 {  // what threadIdx / blockIdx are in the reference's kernels
+    unsigned x = 0, y = 0, z = 0;
+};
+// the grid-stride idiom of the reference's kernels: offset = blockDim * blockIdx + threadIdx, stride = blockDim * gridDim
+inline host_dim3 operator*(host_dim3 a, host_dim3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }   // operators.h:74
+inline host_dim3 operator*(host_dim3 a, host_uint3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // operators.h:84
+inline host_dim3 operator+(host_dim3 a, host_uint3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }  // operators.h:99
 
 inline wav_float2 operator+(wav_float2 a, wav_float2 b) { return {a.x + b.x, a.y + b.y}; }
 inline wav_float2 operator-(wav_float2 a, wav_float2 b) { return {a.x - b.x, a.y - b.y}; }
 inline wav_float2 operator*(wav_float2 a, float s) { return {a.x * s, a.y * s}; }
+inline wav_float2 operator*(float s, wav_float2 a) { return {a.x * s, a.y * s}; }
 inline wav_float2 operator/(wav_float2 a, float s) { return {a.x / s, a.y / s}; }
 inline wav_float2& operator+=(wav_float2& a, wav_float2 b) {
     a.x += b.x;

@@ -58,7 +58,7 @@ typedef struct {
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint64_t n_ref;         /* the reference's fftSize (conv.h:52): IR truncation n_ref-1024
                                (conv.cu:239), Q1/Q2 window and 1/n_ref factors */
-    uint32_t max_batch;     /* largest nblocks accepted by the batch calls (1..262144; host-buffer calls <= 16384) */
+    uint32_t max_batch;     /* largest nblocks accepted by the device-buffer batch calls (1..262144) */
     uint32_t max_partitions;/* 0 = derive from n_ref: ceil((n_ref-1024)/256) */
     uint32_t compat;        /* 1 = bug-compatible with conv.cu (DC/Nyquist terms Q1/Q2);
                                0 = plain linear convolution */
@@ -129,8 +129,17 @@ int mc_handle_cc(mc_engine *e, int half, const uint8_t ccmap[8], uint8_t control
 /* One JACK period: host buffers in, host buffers out, returns when the output
  * is in outL/outR (like onProcess, which blocks on the GPU; conv.cu:455). */
 int mc_process(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nframes);
-/* nblocks consecutive periods, host buffers of nblocks*256 floats */
+/* nblocks consecutive periods, host buffers of nblocks*256 floats: the reference's per-block copies between JACK's
+ * host buffers and the device (conv.cu:321-328, 431-437) for a whole run of blocks.  Any nblocks >= 1 (a multiple of
+ * period/256); long runs are cut into chunks inside (parameters are sampled per chunk).  Pageable buffers (what JACK
+ * hands the reference) go through the engine's pinned staging buffer, one chunk at a time.  Buffers in pinned host
+ * memory - mc_host_alloc, hipHostMalloc or hipHostRegister, all four of them - are read and written by the DMA engines
+ * directly: copy-in, kernels and copy-out of consecutive chunks overlap on three streams (PCIe-bound).  Returns when
+ * the output is complete in outL / outR. */
 int mc_process_batch(mc_engine *e, const float *in1, const float *in2, float *outL, float *outR, uint64_t nblocks);
+/* pinned host memory for mc_process_batch buffers (hipHostMalloc; no reference equivalent - JACK owns its buffers) */
+void *mc_host_alloc(size_t bytes);
+void mc_host_free(void *p);
 /* the same with device-resident buffers (16-byte aligned, as hipMalloc and block-granular slices of it are);
  * asynchronous on the engine's stream */
 int mc_process_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_outL, float *d_outR,

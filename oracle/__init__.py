@@ -72,6 +72,8 @@ def lib():
     L.orc_upols_set_shard.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
     L.orc_upols_partial.argtypes = [C.c_void_p, fp, fp, dp, dp]
     L.orc_upols_finish.argtypes = [C.c_void_p, fp, fp, dp, dp, dp, dp]
+    L.orc_upols_range.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_size_t, dp, dp]
+    L.orc_upols_range_settled.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_size_t, dp, dp]
     L.orc_cpu32_create.restype = C.c_void_p
     L.orc_cpu32_create.argtypes = [fp, fp, C.c_size_t]
     L.orc_cpu32_destroy.argtypes = [C.c_void_p]
@@ -222,6 +224,22 @@ class Upols(_Engine):
         wsum = np.ascontiguousarray(wsum, dtype=np.float64)
         out = np.zeros((2, BLOCK), dtype=np.float64)
         lib().orc_upols_finish(self._h, _fp(in1), _fp(in2), _dp(wsum[0]), _dp(wsum[1]), _dp(out[0]), _dp(out[1]))
+        return out
+
+
+    def range(self, in1, in2, b0, n, settled=False):
+        """Output blocks [b0, b0 + n) of a stream that started cold at block 0 under the parameters now set
+        (constant throughout); in1 / in2 hold at least blocks [0, b0 + n).  float64 [2, n * 256].  The blocks
+        before b0 contribute gains, Q1/Q2 terms and spectra; their partition sums are not run.
+        settled=True: the buffers are an excerpt of a long stream in steady state (cross-fade converged) and b0
+        counts from their start; it must lie beyond one reference length / the longest IR + the predelay."""
+        in1, in2 = _f32(in1), _f32(in2)
+        assert len(in1) >= (b0 + n) * BLOCK and len(in2) >= (b0 + n) * BLOCK
+        out = np.zeros((2, n * BLOCK), dtype=np.float64)
+        f = lib().orc_upols_range_settled if settled else lib().orc_upols_range
+        rc = f(self._h, _fp(in1), _fp(in2), b0, n, _dp(out[0]), _dp(out[1]))
+        if rc:
+            raise ValueError("orc_upols_range failed (%d)" % rc)
         return out
 
 

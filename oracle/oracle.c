@@ -627,6 +627,159 @@ void orc_upols_process(orc_upols *u, const float *in1, const float *in2, double 
     orc_upols_finish(u, in1, in2, wl, wr, outL, outR);
 }
 
+/* Range evaluator: output blocks [b0, b0 + n) of the SAME partitioned form, for a stream that started cold at
+ * block 0 (all state zero, Q6) and whose parameters u->cc stayed constant throughout.  in1 / in2 hold blocks
+ * [0, b0 + n).  What the blocks before b0 leave behind - their cross-fade coefficients (Q7, conv.cu:27,345,353),
+ * their Q1/Q2 terms (conv.cu:47-73) and the spectra the window of the first evaluated block still reaches -
+ * is rebuilt without running their partition sums: O((n + pd/256) * P) instead of O(b0 * P).  Same arithmetic as
+ * orc_upols_partial / orc_upols_finish above (conv.cu:392-401 sum, :403-408 inverse, :411-427 post stage);
+ * test_oracle.py checks it against them and against orc_ref_process.
+ * Returns 0, or -1 for a bad argument / used engine, -2 where the Q8 tail drop would act (not modelled here:
+ * longest IR + 255 + predelay > n_ref). */
+static int upols_range(orc_upols *u, const float *in1, const float *in2, size_t b0, size_t n, double *outL, double *outR,
+                       int settled) {
+    if (!u || !in1 || !in2 || !n || u->t != 0) return -1;
+    orc_cc_value cc[2] = {u->cc[0], u->cc[1]};
+    const up_ir *irs[2] = {&u->ir[cc[0].select], &u->ir[cc[1].select]};
+    if (!irs[0]->H[0] || !irs[1]->H[0]) return -1;
+    const float *in[2] = {in1, in2};
+    const size_t total = b0 + n;
+    const long pd = (long)cc[0].predelay, N = (long)u->n_ref;
+    size_t tmax = irs[0]->taps > irs[1]->taps ? irs[0]->taps : irs[1]->taps;
+    if (u->compat && tmax + 255 + (size_t)pd > u->n_ref) return -2;
+    /* settled: in1 / in2 start somewhere in a stream whose cross-fade has converged (e_i = wet_i for every block
+     * given and for every earlier block that still matters): block 0 of the buffers must then lie beyond the reach
+     * of the first evaluated block - one reference length + the predelay (Q1/Q2 windows, conv.cu:89-100) and the
+     * longest IR + the predelay (partition sums) */
+    if (settled && (b0 * UP_B < (size_t)N + (size_t)pd + 2 * UP_B || b0 * UP_B < tmax + (size_t)pd + 3 * UP_B)) return -3;
+
+    /* per input block: wet gains (Q7 recurrence), Q1/Q2 terms and their prefix sums - cheap, from block 0 */
+    double *G = (double *)malloc(sizeof(double) * total * 4);
+    double *CD = (double *)malloc(sizeof(double) * total * 2), *CQ = (double *)malloc(sizeof(double) * total * 2);
+    double e[2] = {settled ? (double)cc[0].wet : 0.0, settled ? (double)cc[1].wet : 0.0};
+    if (settled) cc[0].vsteps = cc[1].vsteps = 0;
+    const double Nr = (double)u->n_ref;
+    for (size_t t = 0; t < total; t++) {
+        double *g = G + t * 4;
+        for (int i = 0; i < 2; i++) {
+            e[i] += ((double)cc[i].wet - e[i]) / (double)(cc[i].vsteps + 5);
+            if (cc[i].vsteps > 0) cc[i].vsteps--;
+            g[0 * 2 + i] = pan_l(cc[i].panWet) * cc[i].level * e[i];
+            g[1 * 2 + i] = pan_r(cc[i].panWet) * cc[i].level * e[i];
+        }
+        double S[2] = {0, 0}, A[2] = {0, 0};
+        for (int i = 0; i < 2; i++)
+            for (size_t m = 0; m < UP_B; m++) {
+                const double x = in[i][t * UP_B + m];
+                S[i] += x;
+                A[i] += ((m & 1) ? -1.0 : 1.0) * x;
+            }
+        double D[2], Q[2];
+        D[0] = -(g[0 * 2 + 0] * S[1] * irs[0]->sums[1] + g[0 * 2 + 1] * S[1] * irs[1]->sums[0]) / Nr;
+        D[1] = -(g[1 * 2 + 0] * S[0] * irs[0]->sums[1] + g[1 * 2 + 1] * S[1] * irs[1]->sums[1]) / Nr;
+        for (int c = 0; c < 2; c++) Q[c] = -(g[c * 2 + 0] * A[0] * irs[0]->sums[2 + c] + g[c * 2 + 1] * A[1] * irs[1]->sums[2 + c]) / Nr;
+        for (int c = 0; c < 2; c++) {
+            CD[t * 2 + c] = prefix_at(CD, (long)t - 1, c) + (u->compat ? D[c] : 0.0);
+            CQ[t * 2 + c] = prefix_at(CQ, (long)t - 1, c) + (u->compat ? Q[c] : 0.0);
+        }
+    }
+
+    /* first block whose segment is needed: the wet sample b0 * 256 - pd lies in block fb, whose first half also
+     * takes the second half of block fb - 1 */
+    long fb = floordiv((long)(b0 * UP_B) - pd, UP_B) - 1;
+    const size_t m0 = fb > 0 ? (size_t)fb : 0;
+    size_t Pmax = 1;
+    for (int i = 0; i < 2; i++) {
+        size_t ph = u->pe ? (u->pe < irs[i]->P ? u->pe : irs[i]->P) : irs[i]->P;
+        if (ph > Pmax) Pmax = ph;
+    }
+    const size_t x0 = m0 + 1 > Pmax ? m0 + 1 - Pmax : 0; /* first block whose spectrum some evaluated window reaches */
+    const size_t nx = total - x0, nm = total - m0;
+    cplx *X[2];
+    for (int i = 0; i < 2; i++) X[i] = (cplx *)malloc(sizeof(cplx) * nx * UP_BINS);
+    double *seg = (double *)malloc(sizeof(double) * nm * 2 * UP_K); /* [t - m0][c][512] */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (long q = 0; q < (long)(nx * 2); q++) {
+        const size_t t = x0 + (size_t)q / 2;
+        const int i = (int)(q & 1);
+        cplx buf[UP_K];
+        memset(buf, 0, sizeof(buf));
+        for (size_t m = 0; m < UP_B; m++) buf[m] = (cplx){in[i][t * UP_B + m], 0};
+        fft_c(buf, UP_K, -1);
+        memcpy(X[i] + (t - x0) * UP_BINS, buf, sizeof(cplx) * UP_BINS);
+    }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (long q = 0; q < (long)(nm * 2); q++) {
+        const size_t t = m0 + (size_t)q / 2;
+        const int c = (int)(q & 1);
+        cplx Y[UP_K];
+        memset(Y, 0, sizeof(Y));
+        for (int i = 0; i < 2; i++) {
+            const up_ir *ir = irs[i];
+            size_t p_lo = u->pb, p_hi = u->pe ? (u->pe < ir->P ? u->pe : ir->P) : ir->P;
+            for (size_t p = p_lo; p < p_hi && p <= t; p++) {
+                const double g = G[(t - p) * 4 + c * 2 + i];
+                const cplx *Hp = ir->H[c] + p * UP_BINS;
+                const cplx *Xp = X[i] + (t - p - x0) * UP_BINS;
+                for (size_t k = 0; k < UP_BINS; k++) Y[k] = c_add(Y[k], c_scale(c_mul(Hp[k], Xp[k]), g));
+            }
+        }
+        for (size_t k = 1; k < UP_B; k++) Y[UP_K - k] = c_conj(Y[k]);
+        fft_c(Y, UP_K, +1);
+        double *s = seg + ((t - m0) * 2 + c) * UP_K;
+        for (size_t m = 0; m < UP_K; m++) s[m] = Y[m].x / (double)UP_K;
+    }
+    /* overlap-add, predelay, Q1/Q2 window sums, clamp, dry mix: as orc_upols_finish */
+    double dgain[2][2];
+    for (int i = 0; i < 2; i++) {
+        dgain[0][i] = (double)cc[i].dry * pan_l(cc[i].panDry) * cc[i].level;
+        dgain[1][i] = (double)cc[i].dry * pan_r(cc[i].panDry) * cc[i].level;
+    }
+    double *out[2] = {outL, outR};
+    for (int c = 0; c < 2; c++)
+        for (size_t t = b0; t < total; t++)
+            for (size_t m = 0; m < UP_B; m++) {
+                const long tau = (long)(t * UP_B + m), ws = tau - pd;
+                double w = 0.0;
+                if (ws >= 0) {
+                    const size_t wb = (size_t)ws / UP_B, wm = (size_t)ws % UP_B;
+                    /* wb >= m0 + 1 unless the stream itself starts there (m0 == 0) */
+                    w = seg[((wb - m0) * 2 + c) * UP_K + wm];
+                    if (wb > m0) w += seg[((wb - 1 - m0) * 2 + c) * UP_K + UP_B + wm];
+                }
+                long thi = floordiv(tau - pd, UP_B), tlo = floordiv(tau - N, UP_B);
+                if (thi > (long)t) thi = (long)t;
+                const double cd = prefix_at(CD, thi, c) - prefix_at(CD, tlo, c);
+                const double cq = prefix_at(CQ, thi, c) - prefix_at(CQ, tlo, c);
+                const double sign = ((tau - pd) & 1) ? -1.0 : 1.0;
+                const double v = clampd(w + cd + sign * cq, -1, 1);
+                out[c][(t - b0) * UP_B + m] = v + in1[t * UP_B + m] * dgain[c][0] + in2[t * UP_B + m] * dgain[c][1];
+            }
+    free(seg);
+    free(X[0]);
+    free(X[1]);
+    free(G);
+    free(CD);
+    free(CQ);
+    return 0;
+}
+
+int orc_upols_range(orc_upols *u, const float *in1, const float *in2, size_t b0, size_t n, double *outL, double *outR) {
+    return upols_range(u, in1, in2, b0, n, outL, outR, 0);
+}
+
+/* The same for an excerpt of a long-running stream in steady state: in1 / in2 begin at some block of the stream
+ * at which (and for one reference length + predelay before which) the cross-fade coefficients had reached wet_i;
+ * b0 counts from the start of the buffers and must lie beyond the reach stated above (-3 otherwise). */
+int orc_upols_range_settled(orc_upols *u, const float *in1, const float *in2, size_t b0, size_t n, double *outL,
+                            double *outR) {
+    return upols_range(u, in1, in2, b0, n, outL, outR, 1);
+}
+
 /* =============================================================== cpu32 ==== */
 /* float32 uniform-partition overlap-save, the timed CPU baseline ("port").
  * SoA spectra, bin-major, partitions stored reversed next to a doubled ring so

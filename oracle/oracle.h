@@ -86,6 +86,16 @@ void orc_upols_set_shard(orc_upols *u, size_t pb, size_t pe);
 void orc_upols_partial(orc_upols *u, const float *in1, const float *in2, double *wetL, double *wetR);
 void orc_upols_finish(orc_upols *u, const float *in1, const float *in2, const double *wsumL, const double *wsumR,
                       double *outL, double *outR);
+/* range evaluator: output blocks [b0, b0 + n) of a stream that started cold at block 0 with the constant
+ * parameters now in orc_upols_cc(); in1 / in2 hold blocks [0, b0 + n); the blocks before b0 contribute their
+ * gains, Q1/Q2 terms and spectra but their own partition sums are not run (a fresh engine only; honours
+ * orc_upols_set_shard).  0 = ok, -1 bad argument, -2 the Q8 tail drop would act (not modelled). */
+int orc_upols_range(orc_upols *u, const float *in1, const float *in2, size_t b0, size_t n, double *outL, double *outR);
+/* ... for an excerpt of a long stream in steady state (cross-fade converged: e_i = wet_i throughout): the buffers
+ * begin anywhere in the stream, b0 counts from their start and must exceed n_ref + predelay and the longest IR +
+ * predelay by two blocks (-3 otherwise) */
+int orc_upols_range_settled(orc_upols *u, const float *in1, const float *in2, size_t b0, size_t n, double *outL,
+                            double *outR);
 
 /* ---- CPU baseline ("port"): float32 uniform-partition overlap-save, OpenMP
  * over bins, steady-state hot path only (fwd FFT, partition x bin MAC for the

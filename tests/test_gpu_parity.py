@@ -1469,3 +1469,215 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
     want = o.process(x[0, : nchk * 256], x[1, : nchk * 256])
     err = rms(fast[:, : nchk * 256] - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
+@pytest.mark.parametrize("n_ref,taps,level,direct_cmp", [(524288, 441000, 254, True), (2097152, 1323000, 255, False)],
+                         ids=["P1723_fused", "P5168_split"])
+def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, level, direct_cmp):
+    """The launch bench.py times, compared DIRECTLY with the oracle (conv.cu:392-401 restated as the partitioned sum,
+    oracle.Upols.range): device-resident batches of mc_preferred_batch(32768) blocks - 32320 = five whole chunks of
+    the fused 8192-point second-level transform for the 10 s IR, five items per persistent workgroup with window
+    look-ahead; 22432 = two chunks of the split 16384-point form for the 30 s IR - in steady state (second and third
+    batch of the stream).  Oracle blocks: inside chunk 0, across the first chunk boundary, the batch end and the
+    first blocks of the next launch.  For the 10 s IR also the whole batch against the direct-form MAC."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    dev = torch.device("cuda:0")
+    irs = [make_ir(taps, seed=5678), make_ir(taps, seed=5680)]  # bench.py's IRs and parameters
+    p0, p1 = dict(BASE, select=0), dict(BASE, select=1)
+
+    def run(direct):
+        monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")
+        monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
+        c = _conv(fftSize=n_ref, max_batch=32768)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        T = c.preferred_batch(32768)
+        x = make_input(3 * T * 256)
+        d_in = torch.from_numpy(x).to(dev)
+        d_out = torch.zeros(3, 2, T * 256, device=dev)
+        c.enable_kernel_timing(True)
+        levels = []
+        for k in range(3):
+            o = k * T * 256
+            c.process_device(d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr(), d_out[k, 0].data_ptr(), d_out[k, 1].data_ptr(), T)
+            c.sync()
+            levels.append(c.kernel_stats()["fast_levels"])
+        out = d_out.cpu().numpy()
+        c.close()
+        return x, T, out, levels
+
+    x, T, got, levels = run(False)
+    assert T == (32320 if taps == 441000 else 22432)
+    assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
+    chunk = (8192 if level == 254 else 16384) - (-(-((taps + 255) // 256) // 16) * 16) + 1
+    assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
+    ranges = [(T + 100, 256), (T + chunk - 65, 130), (2 * T - 128, 128 + 64)]  # (first block, blocks) in the stream
+    num = den = 0.0
+    for b0, n in ranges:
+        u = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            u.prepare(i, ir)
+        apply_params(u, p0, p1, True)
+        want = u.range(x[0], x[1], b0, n)
+        u.close()
+        flat = np.concatenate([got[1], got[2]], axis=1)  # batches 1 and 2 as one stream starting at block T
+        mine = flat[:, (b0 - T) * 256:(b0 - T + n) * 256]
+        err = rms(mine - want)
+        assert rms(want) > 0.05
+        assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"
+        num += float(((mine - want) ** 2).sum())
+        den += mine.size
+    assert (num / den) ** 0.5 <= RMS_TOL
+    if direct_cmp:
+        _, _, ref, lv = run(True)
+        assert lv[1] == 0
+        d = rms(got[1] - ref[1])
+        assert 0 < d <= 2e-6, f"second-level transform vs direct-form MAC over the whole {T}-block batch: {d:.3e}"
+
+
+def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
+    """k_g2_mac is persistent: a workgroup strides over the (bin, chunk) items and requests part of its next item's
+    window ahead.  Any grid - one workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor
+    of the items, exactly the items, more than the items - gives the same bits; T is not a multiple of the chunk
+    (6465 blocks) or of anything else, so the last chunk is ragged (MCCONV_G2_GRID; bounds argument at the kernel)."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    dev = torch.device("cuda:0")
+    irs = [make_ir(441000, seed=11, norm=0.05), make_ir(420000, seed=13, norm=0.05)]
+    T0, T = 2000, 9001  # settle the cross-fade with a first batch, then 6465 + 2536 blocks = 512 items
+    x = torch.from_numpy(make_input((T0 + T) * 256)).to(dev)
+
+    def run(grid):
+        if grid is None:
+            monkeypatch.delenv("MCCONV_G2_GRID", raising=False)
+        else:
+            monkeypatch.setenv("MCCONV_G2_GRID", str(grid))
+        c = _conv(fftSize=524288, max_batch=T)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, dict(BASE), dict(BASE, select=1), False)
+        out = torch.zeros(2, (T0 + T) * 256, device=dev)
+        c.enable_kernel_timing(True)
+        o = 0
+        for n in (T0, T):
+            c.process_device(x[0, o:].data_ptr(), x[1, o:].data_ptr(), out[0, o:].data_ptr(), out[1, o:].data_ptr(), n)
+            o += n * 256
+        c.sync()
+        assert c.kernel_stats()["fast_levels"] == 254
+        c.close()
+        return out[:, T0 * 256:].cpu().numpy()
+
+    want = run(None)
+    assert rms(want) > 0.01
+    for grid in (1, 7, 8, 100, 255, 511, 512, 513):
+        got = run(grid)
+        assert np.array_equal(got, want), f"MCCONV_G2_GRID={grid}: rms {rms(got - want):.3e}"
+
+
+def test_pinned_host_batches_overlap_copies_and_match(oracle_mod, gpu_lib):
+    """mc_process_batch with pinned caller buffers (mc_host_alloc): chunks of the engine's preferred batch, copy-in /
+    kernels / copy-out on three streams, two chunks in flight - same samples as the staged path for pageable buffers
+    (chunks of 16384 blocks through the engine's pinned buffer) and as the oracle; run lengths that are not whole
+    chunks, longer than max_batch and longer than the old 16384-block cap."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, nb = 32768, 40000
+    irs = [make_ir(30000, seed=7, norm=0.05), make_ir(28000, seed=9, norm=0.05)]
+    x = make_input(nb * 256)
+    p0, p1 = dict(BASE, predelay=200, wet=0.6), dict(BASE, select=1, level=0.9)
+    outs = []
+    for pinned in (False, True):
+        c = _conv(fftSize=n_ref, max_batch=6000)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        if pinned:
+            xin, out = c.pinned_array((2, nb * 256)), c.pinned_array((2, nb * 256))
+            xin[:] = x
+        else:
+            xin, out = x, np.zeros((2, nb * 256), np.float32)
+        o = 0
+        for n in (5, 17000, 6000, nb - 23005):  # 17000 > 16384; the last one: three chunks of <= 6000 and a rest
+            s = slice(o * 256, (o + n) * 256)
+            c.process(xin[0, s], xin[1, s], out[:, s])
+            o += n
+        outs.append(np.array(out))
+        c.close()
+    assert rms(outs[0] - outs[1]) <= 2e-6
+    nchk = 700
+    u = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+    apply_params(u, p0, p1, True)
+    for b0 in (0, 16900, nb - nchk):
+        uu = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            uu.prepare(i, ir)
+        apply_params(uu, p0, p1, True)
+        want = uu.range(x[0], x[1], b0, nchk)
+        err = rms(outs[1][:, b0 * 256:(b0 + nchk) * 256] - want)
+        assert err <= RMS_TOL, f"blocks from {b0}: rms {err:.3e}"
+
+
+def test_config4_partition_shards_at_full_size(oracle_mod, gpu_lib):
+    """BASELINE config 4 at its stated shape, one stereo pair of the four (main.cu:31-39: one Convolution per pair):
+    10 s IRs (441 000 taps, 1723 partitions) sharded over 8 engines - virtual ranks on one GPU, the sum of the partial
+    wet blocks stands in for the RCCL reduce - in batches of the shard's preferred length.  A shard is a 224-tap
+    convolution along the block axis whose window starts part_begin slots earlier, so its long batches take the
+    second-level transform like an unsharded engine's.  Steady-state batch against the range oracle (conv.cu:392-401)."""
+    import torch
+
+    from cuda_audio_amd.sharded import shard_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    dev = torch.device("cuda:0")
+    n_ref, G = 524288, 8
+    irs = [make_ir(441000, seed=5678), make_ir(441000, seed=5680)]
+    p0, p1 = dict(BASE, select=0, predelay=300), dict(BASE, select=1, panWet=0.25)
+    bounds = [shard_bounds(1723, G, g) for g in range(G)]
+    assert bounds[0] == (0, 224) and bounds[-1][1] == 1728
+    shards = [_conv(fftSize=n_ref, max_batch=16384, part_begin=a, part_end=b) for a, b in bounds]
+    for s in shards:
+        for i, ir in enumerate(irs):
+            s.prepare(i, ir)
+        apply_params(s, p0, p1, False)
+    T = shards[0].preferred_batch(16384)
+    assert T == (2 * (8192 - 224 + 1) - 1) // 8 * 8 and all(s.preferred_batch(16384) >= T for s in shards[:-1])
+    x = make_input(2 * T * 256)
+    xin = torch.from_numpy(x).to(dev)
+    got = np.zeros((2, 2 * T * 256), np.float32)
+    for s in shards:
+        s.enable_kernel_timing(True)
+    for k in range(2):
+        sl = xin[:, k * T * 256:(k + 1) * T * 256]
+        total = torch.zeros(2 * T * 256, device=dev)
+        for s in shards:
+            part = torch.zeros(2 * T * 256, device=dev)
+            s.partial_device(sl[0].data_ptr(), sl[1].data_ptr(), part.data_ptr(), T)
+            s.sync()
+            total += part
+        out = torch.zeros(2, T * 256, device=dev)
+        torch.cuda.synchronize()
+        shards[0].finish_device(sl[0].data_ptr(), sl[1].data_ptr(), total.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), T)
+        shards[0].sync()
+        for s in shards[1:]:
+            s.finish_device(None, None, None, None, None, T)
+        got[:, k * T * 256:(k + 1) * T * 256] = out.cpu().numpy()
+    levels = [s.kernel_stats()["fast_levels"] for s in shards]
+    for s in shards:
+        s.close()
+    assert all(lv == 254 for lv in levels), levels  # the steady-state batch: fused second-level form on every shard
+    for b0, n in ((T + 50, 200), (2 * T - 100, 100)):
+        u = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            u.prepare(i, ir)
+        apply_params(u, p0, p1, True)
+        want = u.range(x[0], x[1], b0, n)
+        err = rms(got[:, b0 * 256:(b0 + n) * 256] - want)
+        assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"

@@ -181,3 +181,16 @@ def test_main_flow_with_settings_file(host_built, tmp_path):
     out = res.stdout + res.stderr
     assert out.count("Average convolution runtime") == 2
     assert "Selected GPU" in out
+
+
+def test_operators_subset(host_built):
+    """operators.h subset (reference operators.h:74,84,99,321,325,338,552,786,790,1015,1229): the dim3
+    arithmetic of the kernels' grid-stride idiom and the float2 operators, on fixed operands."""
+    out = subprocess.check_output([TOOL, "operators"]).decode().split()
+    got = dict(line.split("=") for line in out)
+    assert got["offset"] == "1297,1,0"  # blockDim * blockIdx + threadIdx = 256 * 5 + 17, 1 * 1 + 0, 1 * 0 + 0
+    assert got["stride"] == "16384,2,1"  # blockDim * gridDim
+    assert got["add"] == "1.75,2" and got["sub"] == "1.25,-6"
+    assert got["mul"] == "3,-4" and got["lmul"] == "3,-4" and got["div"] == "0.375,-0.5"
+    assert got["addeq"] == "1.75,2" and got["addeqs"] == "2.25,2.5"  # scalar added to both components (operators.h:338)
+    assert got["clamp"] == "1,-1"
