@@ -716,8 +716,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if a.precision == "fp32" else "f16 storage, f32 accumulate",
         "data": "synthetic",
-        "head": git_head(),
     }
+    if git_head():
+        line["head"] = git_head()
     if not sharded:
         r = run_single()
         T, dt, ks = r["T"], r["dt"], r["ks"]
@@ -742,10 +743,13 @@ def main():
             fused = lv == 254
             cb = second_level_bytes(blk, int(ks["partitions"]), fused)
             gbs = cb["total"] / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-            tr = labelled_profile("r2_hbm_traffic.json", "k_g2_mac" if fused else "k_f2")
+            tr = labelled_profile("r2_hbm_traffic.json", "headline")
             traffic = None
-            if tr and int(tr["data"].get("blocks_per_launch", -1)) == int(blk):
-                traffic = tr["data"].get("hbm_bytes_per_launch")
+            if tr:
+                rec = [v for k, v in tr["data"].items() if ("k_g2_mac" if fused else "k_f2_") in k]
+                tr["data"] = rec
+                if rec and all(int(v.get("blocks_per_launch", -1)) == int(blk) for v in rec):
+                    traffic = sum(int(v["hbm_bytes_per_launch"]) for v in rec)
             roofline = dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                              "kernel": "k_g2_mac" if fused else "k_f2_fwd + k_f2_prod"}, **common)
@@ -753,7 +757,7 @@ def main():
             roofline["algorithmic_bytes"] = cb
             if tr:
                 roofline["traffic_source"] = {k: tr[k] for k in ("from", "commit", "note")}
-            bind = labelled_profile("r2_g2_counters.json")
+            bind = labelled_profile("r2_headline_counters.json", "derived") if fused else None
             if bind:
                 roofline["binding_resource"] = bind
             roofline["survey_8d_accounting"] = survey

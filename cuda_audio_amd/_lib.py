@@ -9,7 +9,8 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcconv.so")
+# MCCONV_LIB: another build of the same library (A/B measurements of kernel variants); there is still no CPU path
+LIB_PATH = os.environ.get("MCCONV_LIB") or os.path.join(HERE, "libmcconv.so")
 
 MC_BLOCK = 256
 MC_MAX_PREDELAY = 8192

@@ -25,18 +25,25 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f vx_of(float2 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ float2 vx_to(v2f a) { return make_float2(a.x, a.y); }
-// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+// a b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x): both instructions in ONE asm statement - between two statements the
+// compiler pads a wait state (s_nop) whenever the second reads what the first wrote; inside a statement the
+// hardware's own VALU interlock orders them.  r is written by the first instruction while a and b are still needed:
+// early clobber.
 __device__ __forceinline__ v2f vx_mul(v2f a, v2f b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
     return r;
 }
 // a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
 __device__ __forceinline__ v2f vx_mulc(v2f a, v2f b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
     return r;
 }
 // a - j b = (a.x + b.y, a.y - b.x) and a + j b = (a.x - b.y, a.y + b.x)

@@ -1933,8 +1933,18 @@ __device__ __forceinline__ float2 f2_mul(float2 a, float2 b) { return make_float
 // instructions per radix-16 pass and thread.  From the same arithmetic on float2 structs the compiler re-packs scalar
 // operations through 70 register moves (262 instructions); from plain vector expressions it still materialises the
 // lane-wise negations (186).
+// 8-byte LDS accesses of the second-level transforms, LDS-qualified and volatile: the compiler would otherwise pair
+// neighbours into ds_read2_b64 / ds_write2_b64, which move their 16 bytes per lane at half the rate of two
+// ds_read_b64 (MI355X_MICROARCH.md, LDS table); measured 115 -> 111 us per 32320-block launch of k_g2_mac.
+// MC_LDS_PAIRED builds the paired form for comparison.
+#ifndef MC_LDS_PAIRED
+typedef __attribute__((address_space(3))) volatile v2f lds_vol_v2f;
+__device__ __forceinline__ v2f vx_ld(const float2* p) { return *(const lds_vol_v2f*)(p); }
+__device__ __forceinline__ void vx_st(float2* p, v2f v) { *(lds_vol_v2f*)(p) = v; }
+#else
 __device__ __forceinline__ v2f vx_ld(const float2* p) { return *reinterpret_cast<const v2f*>(p); }
 __device__ __forceinline__ void vx_st(float2* p, v2f v) { *reinterpret_cast<v2f*>(p) = v; }
+#endif
 // (v2f, vx_mul, vx_mulc, vx_add_j, vx_sub_j: fft512.hip.h)
 // radix-4 butterfly in place: forward y_m = sum_n a_n (-j)^(mn), inverse with +j
 template <bool INV>
@@ -2006,27 +2016,40 @@ __device__ __forceinline__ void f2_tw3(float2& a1, float2& a2, float2& a3, float
 // with quarter length 4 Q (butterflies over m = r, r+4, r+8, r+12) and the stage with quarter length Q (m = 4g .. 4g+3).
 // j0 = pos0 mod Q.  Forward: decimation in frequency (butterfly, then twiddle), first the wide stage; the inverse
 // undoes them in the opposite order (conjugate twiddle, then inverse butterfly).
-template <bool INV>
-__device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
-    const int Q = 1 << lq;
-    const int step1 = F2_N >> (lq + 4), step2 = F2_N >> (lq + 2);
+// The sixteenth roots of unity w16^r, r = 1..3.  The four twiddles of a radix-16 pass's wide stage are
+// w^((j0 + Q r) step1) = w^(j0 step1) w16^r (Q step1 = N / 16 in every pass): one table lookup and three products with
+// constants instead of four lookups (each two LDS reads, a product and index arithmetic).
+#define W16_1 v2f{0.92387953251128674f, -0.38268343236508977f}
+#define W16_2 v2f{0.70710678118654752f, -0.70710678118654752f}
+#define W16_3 v2f{0.38268343236508977f, -0.92387953251128674f}
+
+// LDS addresses of a thread's 16 elements: the pad of F2_P / G2_P is one entry per GROUP elements, and in every pass
+// the elements pos0 + Q m are either whole groups apart (Q >= GROUP: (pos0 + Q m) / GROUP = pos0 / GROUP + m Q / GROUP)
+// or inside one group (Q m < GROUP - pos0 mod GROUP by the passes' index maps), so they are base + m x constant:
+// one address per thread and pass, the rest are immediate offsets of the ds instructions.
+template <bool INV, int LQ>
+__device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0) {
+    constexpr int Q = 1 << LQ;
+    constexpr int stride = Q >= 64 ? Q + Q / 64 : Q;
+    constexpr int step1 = F2_N >> (LQ + 4), step2 = F2_N >> (LQ + 2);
+    float2* p = s + F2_P(pos0);
     v2f a[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = vx_ld(&s[F2_P(pos0 + Q * m)]);
+    for (int m = 0; m < 16; m++) a[m] = vx_ld(p + stride * m);
+    const v2f wa = vx_tw(t_lo, t_hi, j0 * step1), w = vx_tw(t_lo, t_hi, j0 * step2);
+    const v2f wr[4] = {wa, vx_mul(wa, W16_1), vx_mul(wa, W16_2), vx_mul(wa, W16_3)};
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             vx_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
-            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], vx_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], wr[r]);
         }
-        const v2f w = vx_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             vx_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
             vx_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
         }
     } else {
-        const v2f w = vx_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             vx_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
@@ -2034,12 +2057,12 @@ __device__ __forceinline__ void f2_pair(float2* s, const float2* t_lo, const flo
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], vx_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], wr[r]);
             vx_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < 16; m++) vx_st(&s[F2_P(pos0 + Q * m)], a[m]);
+    for (int m = 0; m < 16; m++) vx_st(p + stride * m, a[m]);
 }
 
 // the last forward / first inverse stage (quarter length 1, no twiddles): four butterflies per thread on quads of
@@ -2068,13 +2091,13 @@ __device__ __forceinline__ void f2_quads(float2* s, int t) {
 // k_f2_fwd and one in k_f2_prod)
 template <bool QUADS = true>
 __device__ __forceinline__ void f2_forward(float2* s, const float2* t_lo, const float2* t_hi) {
-    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<false>(s, t_lo, t_hi, t, t, 10);  // quarter lengths 4096, 1024
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<false, 10>(s, t_lo, t_hi, t, t);  // quarter lengths 4096, 1024
     __syncthreads();
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
-        f2_pair<false>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63, 6);  // 256, 64
+        f2_pair<false, 6>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63);  // 256, 64
     __syncthreads();
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
-        f2_pair<false>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);  // 16, 4
+        f2_pair<false, 2>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8);  // 16, 4
     __syncthreads();
     if (QUADS) {
         for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_quads<false>(s, t);  // 1
@@ -2090,12 +2113,12 @@ __device__ __forceinline__ void f2_inverse(float2* s, const float2* t_lo, const 
         __syncthreads();
     }
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
-        f2_pair<true>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8, 2);
+        f2_pair<true, 2>(s, t_lo, t_hi, ((t & 255) << 6) + (t >> 8), t >> 8);
     __syncthreads();
     for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS)
-        f2_pair<true>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63, 6);
+        f2_pair<true, 6>(s, t_lo, t_hi, ((t >> 6) << 10) + (t & 63), t & 63);
     __syncthreads();
-    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<true>(s, t_lo, t_hi, t, t, 10);
+    for (int t = threadIdx.x; t < F2_PIECES; t += F2_THREADS) f2_pair<true, 10>(s, t_lo, t_hi, t, t);
     __syncthreads();
 }
 
@@ -2317,30 +2340,32 @@ __device__ __forceinline__ void g2_tables(float2* t_lo, float2* t_hi) {  // w = 
 }
 
 // two consecutive radix-4 stages (quarter lengths 4 Q and Q) on the 16 elements pos0 + Q m of a thread; see f2_pair
-template <bool INV>
-__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, int lq) {
-    const int Q = 1 << lq;
-    const int step1 = G2_N >> (lq + 4), step2 = G2_N >> (lq + 2);
-    // LDS addresses are recomputed in every pass: shared between the forward and the inverse transform they would stay
+template <bool INV, int LQ>
+__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0) {
+    constexpr int Q = 1 << LQ;
+    constexpr int stride = Q >= 32 ? Q + Q / 32 : Q;  // elements Q apart: whole pad groups apart, or inside one (see f2_pair)
+    constexpr int step1 = G2_N >> (LQ + 4), step2 = G2_N >> (LQ + 2);
+    // the LDS address is recomputed in every pass: shared between the forward and the inverse transform it would stay
     // live across the whole kernel and spill
     asm volatile("" : "+v"(pos0), "+v"(j0));
+    float2* p = s + G2_P(pos0);
     v2f a[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = vx_ld(&s[G2_P(pos0 + Q * m)]);
+    for (int m = 0; m < 16; m++) a[m] = vx_ld(p + stride * m);
+    const v2f wa = vg_tw(t_lo, t_hi, j0 * step1), w = vg_tw(t_lo, t_hi, j0 * step2);
+    const v2f wr[4] = {wa, vx_mul(wa, W16_1), vx_mul(wa, W16_2), vx_mul(wa, W16_3)};
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             vx_bfly4<false>(a[r], a[r + 4], a[r + 8], a[r + 12]);
-            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], vg_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_tw3<false>(a[r + 4], a[r + 8], a[r + 12], wr[r]);
         }
-        const v2f w = vg_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             vx_bfly4<false>(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
             vx_tw3<false>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
         }
     } else {
-        const v2f w = vg_tw(t_lo, t_hi, j0 * step2);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             vx_tw3<true>(a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], w);
@@ -2348,12 +2373,12 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], vg_tw(t_lo, t_hi, (j0 + Q * r) * step1));
+            vx_tw3<true>(a[r + 4], a[r + 8], a[r + 12], wr[r]);
             vx_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < 16; m++) vx_st(&s[G2_P(pos0 + Q * m)], a[m]);
+    for (int m = 0; m < 16; m++) vx_st(p + stride * m, a[m]);
 }
 
 // the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
@@ -2373,11 +2398,11 @@ __device__ __forceinline__ void g2_pairs2(float2* s, int tt) {
 // thread owns while it forms the products, and again before the inverse: two trips through LDS less)
 template <bool PAIRS2 = true>
 __device__ __forceinline__ void g2_forward(float2* s, const float2* t_lo, const float2* t_hi, int tt) {
-    g2_pair<false>(s, t_lo, t_hi, tt, tt, 9);  // quarter lengths 2048, 512
+    g2_pair<false, 9>(s, t_lo, t_hi, tt, tt);  // quarter lengths 2048, 512
     __syncthreads();
-    g2_pair<false>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31, 5);  // 128, 32
+    g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);  // 128, 32
     __syncthreads();
-    g2_pair<false>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);  // 8, 2
+    g2_pair<false, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);  // 8, 2
     __syncthreads();
     if (PAIRS2) {
         g2_pairs2(s, tt);
@@ -2390,11 +2415,11 @@ __device__ __forceinline__ void g2_inverse(float2* s, const float2* t_lo, const 
         g2_pairs2(s, tt);
         __syncthreads();
     }
-    g2_pair<true>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8, 1);
+    g2_pair<true, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
     __syncthreads();
-    g2_pair<true>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31, 5);
+    g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
     __syncthreads();
-    g2_pair<true>(s, t_lo, t_hi, tt, tt, 9);
+    g2_pair<true, 9>(s, t_lo, t_hi, tt, tt);
     __syncthreads();
 }
 
@@ -2477,12 +2502,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
     const int xq = item >> 3;
     const int bin = (xq / nch) * 8 + (item & 7), chunk = xq % nch;
     const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0);
+    {
+        // element n = tid + 1024 r sits at G2_P(tid) + r (1024 + 32): one address, immediate offsets
+        int t0 = threadIdx.x;
+        asm volatile("" : "+v"(t0));
+        float2* w0 = &s[0][G2_P(t0)];
 #pragma unroll
-    for (int r = 0; r < G2_N / G2_THREADS; r++) {
-        const int n = threadIdx.x + G2_THREADS * r;
-        const float4 x = r < G2_PW ? xw[r] : window_row(item, r);
-        s[0][G2_P(n)] = make_float2(x.x, x.y);
-        s[1][G2_P(n)] = make_float2(x.z, x.w);
+        for (int r = 0; r < G2_N / G2_THREADS; r++) {
+            const float4 x = r < G2_PW ? xw[r] : window_row(item, r);
+            w0[r * (G2_THREADS + G2_THREADS / 32)] = make_float2(x.x, x.y);
+            w0[G2_LDS + r * (G2_THREADS + G2_THREADS / 32)] = make_float2(x.z, x.w);
+        }
     }
     __syncthreads();
     g2_forward<false>(s[half], t_lo, t_hi, tt);
@@ -2524,7 +2554,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                     S0.y = -S0.y;
                     S1.y = -S1.y;
                 } else {
-                    const v2f a = vx_ld(&s[i][G2_P(idx)]), b = vx_ld(&s[i][G2_P(idx + 1)]);
+                    // entries 2 j, 2 j + 1 (j = tid + 1024 r) share a pad group: G2_P(2 tid) + r (2048 + 64), and + 1
+                    const float2* pp = &s[i][G2_P(2 * (j - G2_THREADS * r))] + r * (2 * G2_THREADS + 2 * G2_THREADS / 32);
+                    const v2f a = vx_ld(pp), b = vx_ld(pp + 1);
                     S0 = a + b;
                     S1 = a - b;
                 }
@@ -2555,13 +2587,18 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         }
     }
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
+    {
+        int t0 = threadIdx.x;
+        asm volatile("" : "+v"(t0));
+        float2* y0 = &s[0][G2_P(2 * t0)];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int idx = 2 * (threadIdx.x + G2_THREADS * r);
-        vx_st(&s[0][G2_P(idx)], yl[2 * r]);
-        vx_st(&s[0][G2_P(idx + 1)], yl[2 * r + 1]);
-        vx_st(&s[1][G2_P(idx)], yr[2 * r]);
-        vx_st(&s[1][G2_P(idx + 1)], yr[2 * r + 1]);
+        for (int r = 0; r < 4; r++) {
+            constexpr int RS = 2 * G2_THREADS + 2 * G2_THREADS / 32;
+            vx_st(y0 + r * RS, yl[2 * r]);
+            vx_st(y0 + r * RS + 1, yl[2 * r + 1]);
+            vx_st(y0 + G2_LDS + r * RS, yr[2 * r]);
+            vx_st(y0 + G2_LDS + r * RS + 1, yr[2 * r + 1]);
+        }
     }
     __syncthreads();
     if (item + (int)gridDim.x < nitems) {
