@@ -2325,6 +2325,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #ifndef G2_PF
 #define G2_PF 2  // groups of product entries whose spectra are loaded together
 #endif
+#ifndef G2_AHEAD
+#define G2_AHEAD 0  // 1: the first G2_PF groups' spectra are requested before the forward transforms
+#endif
 
 __device__ __forceinline__ float2 g2_tw(const float2* t_lo, const float2* t_hi, int e) { return f2_mul(t_lo[e & 127], t_hi[e >> 7]); }
 __device__ __forceinline__ v2f vg_tw(const float2* t_lo, const float2* t_hi, int e) { return vx_mul(vx_ld(t_lo + (e & 127)), vx_ld(t_hi + (e >> 7))); }
@@ -2459,6 +2462,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__
     for (int i = tt; i < G2_N; i += 512) dst[i] = s[c][G2_P(i)];
 }
 
+// k_g2_mac_wide: the one-workgroup-per-CU form (MCCONV_G2_WIDE=1; kept as the measured alternative of k_g2_mac below).
 // grid = 256 bins x chunks, block = 1024 (two halves: input 1 / input 2, later Y_L / Y_R).
 // chunk_t + taps - 1 <= G2_N.
 // Bounds of every global access (host checks: nitems = 256 * ceil(T / chunk_t), T <= ycap, ring a power of two,
@@ -2474,8 +2478,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_ir(const float4* __restrict__
 //            the compiler hoisting the address arithmetic above the transforms; its value is unchanged.
 //   sums     Yc[bin * ycap + t_c0 + t], t < nout = min(chunk_t, T - t_c0): t_c0 + t < T <= ycap.
 // LDS: G2_P(n) <= G2_P(8191) = 8446 < G2_LDS; the mirrored positions of bin 0 are permutations of [0, G2_N).
-__global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
-                                                       int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
+__global__ __launch_bounds__(G2_THREADS) void k_g2_mac_wide(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                            int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
     __shared__ float2 s[2][G2_LDS];
     __shared__ float2 t_lo[128], t_hi[64];
     // block ids 8 apart run on one XCD: there the chunks of a bin follow each other, so that the bin's second-level
@@ -2515,30 +2519,32 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
         }
     }
     __syncthreads();
-    g2_forward<false>(s[half], t_lo, t_hi, tt);
-    // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers - the pairs of the
-    // transforms' radix-2 stage, which is applied here on the way in and on the way out
-    v2f yl[8], yr[8];
-#pragma unroll
-    for (int rp = 0; rp < 4; rp += G2_PF) {
-        // the spectra of the first voice for G2_PF groups of entries at a time: 4 G2_PF loads of 16 bytes in flight per
-        // thread (requesting the first batch ahead of the window fill, or all four groups at once, was no faster)
-        float4 HLp[G2_PF][2], HRp[G2_PF][2];
+    // The spectra of the first voice, G2_PF groups of product entries (4 G2_PF loads of 16 bytes per thread) at a time.
+    // 32-bit byte offsets from the (wave-uniform) row bases: scalar base + vector offset addressing, no 64-bit
+    // vector arithmetic.
+    auto load_spectra = [&](int rp, float4 (&HLp)[G2_PF][2], float4 (&HRp)[G2_PF][2]) {
 #pragma unroll
         for (int r2 = 0; r2 < G2_PF; r2++)
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                int j = threadIdx.x + G2_THREADS * (rp + r2);
-                asm volatile("" : "+v"(j));  // addresses of this group are formed here, not ahead of the transforms
-                const float2* h = (i == 0 ? vv.h0[0] : vv.h1[0]) + (size_t)bin * G2_N;
-                HLp[r2][i] = reinterpret_cast<const float4*>(h)[j];
-                HRp[r2][i] = reinterpret_cast<const float4*>(h + (size_t)257 * G2_N)[j];
+                unsigned off = (threadIdx.x + G2_THREADS * (unsigned)(rp + r2)) * 16u;
+                asm volatile("" : "+v"(off));  // addresses of this group are formed here, not ahead of the transforms
+                const char* h = reinterpret_cast<const char*>((i == 0 ? vv.h0[0] : vv.h1[0]) + (size_t)bin * G2_N);
+                HLp[r2][i] = *reinterpret_cast<const float4*>(h + off);
+                HRp[r2][i] = *reinterpret_cast<const float4*>(h + (size_t)257 * G2_N * sizeof(float2) + off);
             }
+    };
+    // products in place: thread owns entries 2j, 2j + 1 (j = tid + 1024 r) of both buffers - the pairs of the
+    // transforms' radix-2 stage, which is applied here on the way in and on the way out
+    v2f yl[8], yr[8];
+    auto products = [&](int rp, const float4 (&HLp)[G2_PF][2], const float4 (&HRp)[G2_PF][2]) {
 #pragma unroll
         for (int r2 = 0; r2 < G2_PF; r2++) {
             const int r = rp + r2;
-            int j = threadIdx.x + G2_THREADS * r;
-            asm volatile("" : "+v"(j));
+            int t0 = threadIdx.x;
+            asm volatile("" : "+v"(t0));
+            const int j = t0 + G2_THREADS * r;
+            const unsigned off = (unsigned)j * 16u;
             const int idx = 2 * j;
             v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
             for (int q = 0; q < (bin == 0 ? 4 : 2); q++) {
@@ -2555,7 +2561,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                     S1.y = -S1.y;
                 } else {
                     // entries 2 j, 2 j + 1 (j = tid + 1024 r) share a pad group: G2_P(2 tid) + r (2048 + 64), and + 1
-                    const float2* pp = &s[i][G2_P(2 * (j - G2_THREADS * r))] + r * (2 * G2_THREADS + 2 * G2_THREADS / 32);
+                    const float2* pp = &s[i][G2_P(2 * t0)] + r * (2 * G2_THREADS + 2 * G2_THREADS / 32);
                     const v2f a = vx_ld(pp), b = vx_ld(pp + 1);
                     S0 = a + b;
                     S1 = a - b;
@@ -2571,8 +2577,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
                         HL = i == 0 ? HLp[r2][0] : HLp[r2][1];
                         HR = i == 0 ? HRp[r2][0] : HRp[r2][1];
                     } else {
-                        HL = reinterpret_cast<const float4*>(h + row)[j];
-                        HR = reinterpret_cast<const float4*>(h + row + (size_t)257 * G2_N)[j];
+                        const char* hb = reinterpret_cast<const char*>(h + row);
+                        HL = *reinterpret_cast<const float4*>(hb + off);
+                        HR = *reinterpret_cast<const float4*>(hb + (size_t)257 * G2_N * sizeof(float2) + off);
                     }
                     aL0 += gl * vx_mul(S0, v2f{HL.x, HL.y});
                     aL1 += gl * vx_mul(S1, v2f{HL.z, HL.w});
@@ -2585,7 +2592,26 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
             yr[2 * r] = aR0 + aR1;
             yr[2 * r + 1] = aR0 - aR1;
         }
+    };
+#if G2_AHEAD
+    // the first G2_PF groups are requested before the forward transforms and arrive under them; the rest at the start
+    // of the products, so that all of an item's spectra are in flight or in registers before the first product
+    static_assert(2 * G2_PF == 4, "G2_AHEAD splits the four groups in two batches");
+    float4 HLa[G2_PF][2], HRa[G2_PF][2], HLb[G2_PF][2], HRb[G2_PF][2];
+    load_spectra(0, HLa, HRa);
+    g2_forward<false>(s[half], t_lo, t_hi, tt);
+    load_spectra(G2_PF, HLb, HRb);
+    products(0, HLa, HRa);
+    products(G2_PF, HLb, HRb);
+#else
+    g2_forward<false>(s[half], t_lo, t_hi, tt);
+#pragma unroll
+    for (int rp = 0; rp < 4; rp += G2_PF) {
+        float4 HLp[G2_PF][2], HRp[G2_PF][2];
+        load_spectra(rp, HLp, HRp);
+        products(rp, HLp, HRp);
     }
+#endif
     __syncthreads();  // bin 0 reads mirrored entries that other threads own: every read before any write
     {
         int t0 = threadIdx.x;
@@ -2614,4 +2640,227 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac(const float4* __restrict_
     }
     __syncthreads();  // the buffers are free for the next item
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_g2_mac: the fused second-level transform with TWO workgroups per CU.
+// The one-workgroup form above keeps both inputs' sequences in LDS side by side (133 KB): its phases - window fill,
+// forward transforms, products (the spectra stream in), inverse transforms, store - cannot overlap, and its counters
+// say so (profiles/r2_headline_summary.md: waves parked at s_waitcnt / barriers half of their time, VALU 43 % busy,
+// LDS 26 %, 2.4 of 8 TB/s).  Here a workgroup of 512 threads owns ONE 8192-point LDS buffer (67.6 KB) and runs the two
+// sequences of its item through it one after the other; what has to wait for the buffer waits in registers:
+//   window -> x1 to LDS, x2 held (16 entries per thread) -> forward(x1) -> own spectrum entries of X1 to registers
+//   -> x2 to LDS -> forward(x2) -> products: X1 from registers, X2 and Y_L in place in LDS, Y_R into X1's registers
+//   -> inverse(Y_L) -> its valid outputs to registers -> Y_R to LDS -> inverse(Y_R) -> {Y_L, Y_R} stored 16 bytes per block.
+// Two such workgroups share a CU (2 x 69 KB of LDS, 2 x 8 waves at <= 128 VGPRs), each in its own phase: one's memory
+// phases run under the other's transforms.  Same arithmetic, same order of operations per entry as the one-workgroup
+// form, except for bin 0.
+// Bin 0 packs {DC, Nyquist} as one complex number z and needs y = h1 * z + h2 * conj(z).  The one-workgroup form
+// takes the spectrum of conj(z) from mirrored entries of the spectrum of z, which here sit in other threads'
+// registers; instead the item runs twice - inputs z with rows h1, then inputs conj(z) (conjugated as the window is
+// read) with rows h2 (row 256), the second run adding to the sums the first one stored.  One item in 256.
+// Bounds: as for the one-workgroup form above (items, window, spectra rows, sums); LDS: G2_P(8191) < G2_LDS.
+// ---------------------------------------------------------------------------
+#define G2B_THREADS 512
+#ifndef G2B_AHEAD
+#define G2B_AHEAD 1  // entry pairs by which the spectra loads run ahead of the products (4 loads of 16 bytes each)
+#endif
+#ifndef G2B_FILL
+#define G2B_FILL 16  // window rows requested together (all of them: one round of memory latency)
+#endif
+__global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                           int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
+    __shared__ float2 s[G2_LDS];
+    __shared__ float2 t_lo[128], t_hi[64];
+    const int nch = nitems >> 8;
+    g2_tables(t_lo, t_hi);
+#if G2_STAMPS  // diagnostic build only: where a workgroup's time goes (s_memtime ticks = shader cycles)
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_now;
+    int st_items = 0;
+#define G2_STAMP(k)                                                                       \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if ((k) >= 0) st_acc[(k) < 0 ? 0 : (k)] += st_now - st_prev;                      \
+        st_prev = st_now;                                                                 \
+    } while (0)
+#else
+#define G2_STAMP(k) do { } while (0)
+#endif
+    constexpr int ROWS = G2_N / G2B_THREADS;        // 16 window entries per thread and sequence
+    constexpr int WS = G2B_THREADS + G2B_THREADS / 32;  // LDS distance of entries 512 apart
+    constexpr int PS = 2 * G2B_THREADS + 2 * G2B_THREADS / 32;  // ... of entry pairs 2 j, 2 (j + 512)
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int xq = item >> 3;
+        const int bin = (xq / nch) * 8 + (item & 7), chunk = xq % nch;
+        const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+        const float4* fk = fdl + (size_t)bin * ring;
+        const int sb = slot0 + t_c0 - (taps - 1);
+        for (int pass = 0; pass < (bin == 0 ? 2 : 1); pass++) {
+            const float cj = pass ? -1.0f : 1.0f;  // second run of bin 0: conj(z)
+            const int row = pass ? 256 : bin;
+            int tt = threadIdx.x;
+            asm volatile("" : "+v"(tt));
+            G2_STAMP(-1);
+            // ---- window: 16 bytes per slot carry both inputs; x1 to LDS, x2 waits in registers
+            v2f x2[ROWS];
+            {
+                float2* w0 = &s[G2_P(tt)];
+#pragma unroll
+                for (int r0 = 0; r0 < ROWS; r0 += G2B_FILL) {
+                    float4 x[G2B_FILL];
+#pragma unroll
+                    for (int r = 0; r < G2B_FILL; r++) {
+                        const int n = tt + G2B_THREADS * (r0 + r);
+                        x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (n < L) x[r] = fk[(sb + n) & (ring - 1)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < G2B_FILL; r++) {
+                        vx_st(w0 + (r0 + r) * WS, v2f{x[r].x, cj * x[r].y});
+                        x2[r0 + r] = v2f{x[r].z, cj * x[r].w};
+                    }
+                }
+            }
+            __syncthreads();
+            G2_STAMP(0);
+            g2_forward<false>(s, t_lo, t_hi, tt);
+            G2_STAMP(1);
+            // ---- own entries of X1 (pairs 2 j, 2 j + 1, j = tt + 512 r; the radix-2 stage on the way) to registers
+            v2f X1[ROWS];
+            {
+                asm volatile("" : "+v"(tt));
+                const float2* pp = &s[G2_P(2 * tt)];
+#pragma unroll
+                for (int r = 0; r < ROWS / 2; r++) {
+                    const v2f a = vx_ld(pp + r * PS), b = vx_ld(pp + r * PS + 1);
+                    X1[2 * r] = a + b;
+                    X1[2 * r + 1] = a - b;
+                }
+            }
+            __syncthreads();
+            {
+                asm volatile("" : "+v"(tt));
+                float2* w0 = &s[G2_P(tt)];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) vx_st(w0 + r * WS, x2[r]);
+            }
+            __syncthreads();
+            G2_STAMP(2);
+            g2_forward<false>(s, t_lo, t_hi, tt);
+            G2_STAMP(3);
+            // ---- products: Y_c = sum_voices g (X1 H1c + X2 H2c) on the thread's own entries; Y_L replaces X2 in LDS,
+            // Y_R replaces X1 in registers.  The first voice's spectra run G2B_AHEAD entry pairs ahead of the arithmetic
+            // (4 loads of 16 bytes per pair, a ring of G2B_AHEAD + 1 pairs in registers).
+            {
+                asm volatile("" : "+v"(tt));
+                float2* pp = &s[G2_P(2 * tt)];
+                constexpr int NP = ROWS / 2, RING = G2B_AHEAD + 1;
+                float4 HLq[RING][2], HRq[RING][2];
+                const char* hrow[2] = {reinterpret_cast<const char*>(vv.h0[0] + (size_t)row * G2_N),
+                                       reinterpret_cast<const char*>(vv.h1[0] + (size_t)row * G2_N)};
+                auto request = [&](int r) {
+                    const unsigned off = ((unsigned)tt + G2B_THREADS * (unsigned)r) * 16u;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        HLq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + off);
+                        HRq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + (size_t)257 * G2_N * sizeof(float2) + off);
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < G2B_AHEAD; r++) request(r);
+#pragma unroll
+                for (int r = 0; r < NP; r++) {
+                    if (r + G2B_AHEAD < NP) request(r + G2B_AHEAD);
+                    const unsigned off = ((unsigned)tt + G2B_THREADS * (unsigned)r) * 16u;
+                    const v2f a = vx_ld(pp + r * PS), b = vx_ld(pp + r * PS + 1);
+                    const v2f S[2][2] = {{X1[2 * r], X1[2 * r + 1]}, {a + b, a - b}};
+                    v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+#pragma unroll
+                        for (int vi = 0; vi < MC_MAXV; vi++) {
+                            if (vi >= vv.n) break;
+                            const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
+                            float4 HL, HR;
+                            if (vi == 0) {
+                                HL = HLq[r % RING][i];
+                                HR = HRq[r % RING][i];
+                            } else {
+                                const char* hb = reinterpret_cast<const char*>((i == 0 ? vv.h0[vi] : vv.h1[vi]) + (size_t)row * G2_N);
+                                HL = *reinterpret_cast<const float4*>(hb + off);
+                                HR = *reinterpret_cast<const float4*>(hb + (size_t)257 * G2_N * sizeof(float2) + off);
+                            }
+                            aL0 += gl * vx_mul(S[i][0], v2f{HL.x, HL.y});
+                            aL1 += gl * vx_mul(S[i][1], v2f{HL.z, HL.w});
+                            aR0 += gr * vx_mul(S[i][0], v2f{HR.x, HR.y});
+                            aR1 += gr * vx_mul(S[i][1], v2f{HR.z, HR.w});
+                        }
+                    }
+                    vx_st(pp + r * PS, aL0 + aL1);  // the inverse transform's radix-2 stage on the way out
+                    vx_st(pp + r * PS + 1, aL0 - aL1);
+                    X1[2 * r] = aR0 + aR1;
+                    X1[2 * r + 1] = aR0 - aR1;
+                    __builtin_amdgcn_sched_barrier(0);  // requests stay G2B_AHEAD pairs ahead, no further (registers)
+                }
+            }
+            __syncthreads();
+            G2_STAMP(4);
+            g2_inverse<false>(s, t_lo, t_hi, tt);
+            G2_STAMP(5);
+            // ---- the valid part of the circle (its first taps - 1 outputs are discarded) of Y_L to registers
+            v2f yl[ROWS];
+            {
+                asm volatile("" : "+v"(tt));
+                const float2* q0 = &s[G2_P(tt + taps - 1)];
+#pragma unroll
+                for (int k = 0; k < ROWS; k++)
+                    if (tt + G2B_THREADS * k < nout) yl[k] = vx_ld(q0 + k * WS);
+            }
+            __syncthreads();
+            {
+                asm volatile("" : "+v"(tt));
+                float2* pp = &s[G2_P(2 * tt)];
+#pragma unroll
+                for (int r = 0; r < ROWS / 2; r++) {
+                    vx_st(pp + r * PS, X1[2 * r]);
+                    vx_st(pp + r * PS + 1, X1[2 * r + 1]);
+                }
+            }
+            __syncthreads();
+            G2_STAMP(6);
+            g2_inverse<false>(s, t_lo, t_hi, tt);
+            G2_STAMP(7);
+            {
+                asm volatile("" : "+v"(tt));
+                const float sc = 1.0f / (float)G2_N;
+                const float2* q0 = &s[G2_P(tt + taps - 1)];
+                float4* dst = Yc + (size_t)bin * ycap + t_c0;
+#pragma unroll
+                for (int k = 0; k < ROWS; k++) {
+                    const int t = tt + G2B_THREADS * k;
+                    if (t < nout) {
+                        const v2f yr = vx_ld(q0 + k * WS);
+                        float4 y = make_float4(yl[k].x * sc, yl[k].y * sc, yr.x * sc, yr.y * sc);  // (second run of bin 0: h2 * conj z)
+                        if (pass) {
+                            const float4 o = dst[t];
+                            y = make_float4(o.x + y.x, o.y + y.y, o.z + y.z, o.w + y.w);
+                        }
+                        dst[t] = y;
+                    }
+                }
+            }
+            __syncthreads();  // the buffer is free for the next run
+            G2_STAMP(8);
+#if G2_STAMPS
+            st_items++;
+#endif
+        }
+    }
+#if G2_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137 || blockIdx.x == 300 || blockIdx.x == 511))
+        printf("g2 wg %d items %d: fill %llu fwd1 %llu x1regs+x2fill %llu fwd2 %llu products %llu inv1 %llu out1+yrfill %llu inv2 %llu store %llu\n",
+               (int)blockIdx.x, st_items, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8]);
+#endif
 }

@@ -182,7 +182,8 @@ struct mc_engine {
     bool fft2 = true;     // long batches: second-level transform along the block axis instead of the MAC
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
-    int g2_grid = 256;       // workgroups of k_g2_mac: one per CU (set at create), each loops over its (bin, chunk) items; MCCONV_G2_GRID
+    int g2_grid = 1 << 30;   // workgroups of k_g2_mac, capped by the number of (bin, chunk) items (default: one per item); MCCONV_G2_GRID
+    bool g2_wide = false;    // MCCONV_G2_WIDE=1: the one-workgroup-per-CU form of the kernel (1024 threads, both sequences in LDS)
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     bool inv_to_wet = true;  // whole-batch path: k_inv_wet + ring-reading k_post (MCCONV_INV_WET=0: k_inv + segment ring)
@@ -804,8 +805,12 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                         fprintf(stderr, "  G2[%d] in1 [%p, %p) in2 [%p, %p)\n", a, (void*)vv.h0[a], (void*)(vv.h0[a] + (size_t)2 * 257 * G2_N),
                                 (void*)vv.h1[a], (void*)(vv.h1[a] + (size_t)2 * 257 * G2_N));
                 }
-                hipLaunchKernelGGL(k_g2_mac, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0,
-                                   T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
+                if (e->g2_wide)  // the one-workgroup-per-CU form (MCCONV_G2_WIDE=1)
+                    hipLaunchKernelGGL(k_g2_mac_wide, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl,
+                                       e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
+                else
+                    hipLaunchKernelGGL(k_g2_mac, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2B_THREADS), 0, e->stream, e->d_fdl, e->ring,
+                                       slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
                 mo->ysrc = e->d_Yc;
                 mo->sk = e->Tcap;
                 mo->stt = 1;
@@ -1793,7 +1798,12 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
     {
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) e->g2_grid = cus & ~7;
+        if (const char* gw = std::getenv("MCCONV_G2_WIDE")) e->g2_wide = std::atoi(gw) != 0;
+        // k_g2_mac: one workgroup per (bin, chunk) item - the dispatcher keeps two resident per CU and hands a CU its next
+        // one the moment a slot frees (measured against 512 persistent workgroups striding over 1280 items: 98 vs 108 us).
+        // The one-workgroup-per-CU form is persistent (one per CU, look-ahead into its next item).
+        e->g2_grid = 1 << 30;
+        if (e->g2_wide) e->g2_grid = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) ? (cus & ~7) : 256;
     }
     // (any grid >= 1 is correct: a workgroup strides over the items; multiples of 8 keep a bin's chunks on one XCD)
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
