@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""The JACK path in a loop (one 256-frame period per mc_process call, config 3) - the program scripts/profile_jack.sh
+runs under rocprofv3.  Prints microseconds per call."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cuda_audio_amd.engine import Convolution  # noqa: E402
+from cuda_audio_amd.synth import make_input, make_ir  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+c = Convolution("jack", 524288, max_batch=8, device=0)
+c.prepare(0, make_ir(441000, seed=5678))
+c.prepare(1, make_ir(441000, seed=5680))
+for h in (0, 1):
+    c.cc[h].value.update(select=h, vsteps=0)
+x = make_input(256)
+fp = C.POINTER(C.c_float)
+bufs = [np.ascontiguousarray(x[0]), np.ascontiguousarray(x[1]), np.zeros(256, np.float32), np.zeros(256, np.float32)]
+p = [b.ctypes.data_as(fp) for b in bufs]
+for _ in range(300):
+    c._L.mc_process(c._h, p[0], p[1], p[2], p[3], 256)
+t0 = time.perf_counter()
+for _ in range(n):
+    c._L.mc_process(c._h, p[0], p[1], p[2], p[3], 256)
+dt = (time.perf_counter() - t0) / n
+print(f"{dt * 1e6:.2f} us per 256-frame call, {256 / 44100 / dt:.1f} x real time, avgRuntime {c.avgRuntime() * 1e3:.2f} us")
+c.close()
