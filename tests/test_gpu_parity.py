@@ -1540,10 +1540,11 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
 
 
 def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
-    """k_g2_mac is persistent: a workgroup strides over the (bin, chunk) items and requests part of its next item's
-    window ahead.  Any grid - one workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor
-    of the items, exactly the items, more than the items - gives the same bits; T is not a multiple of the chunk
-    (6465 blocks) or of anything else, so the last chunk is ragged (MCCONV_G2_GRID; bounds argument at the kernel)."""
+    """k_g2_mac's workgroups stride over the (bin, chunk) items (default: one workgroup per item).  Any grid - one
+    workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor of the items, exactly the items,
+    more than the items - gives the same bits; T is not a multiple of the chunk (6465 blocks) or of anything else, so
+    the last chunk is ragged (MCCONV_G2_GRID; bounds argument at the kernel).  The same for the
+    one-workgroup-per-CU form with its look-ahead into the next item (MCCONV_G2_WIDE=1)."""
     import torch
 
     from cuda_audio_amd.synth import make_input, make_ir
@@ -1553,7 +1554,8 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     T0, T = 2000, 9001  # settle the cross-fade with a first batch, then 6465 + 2536 blocks = 512 items
     x = torch.from_numpy(make_input((T0 + T) * 256)).to(dev)
 
-    def run(grid):
+    def run(grid, wide=False):
+        monkeypatch.setenv("MCCONV_G2_WIDE", "1" if wide else "0")
         if grid is None:
             monkeypatch.delenv("MCCONV_G2_GRID", raising=False)
         else:
@@ -1578,6 +1580,11 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     for grid in (1, 7, 8, 100, 255, 511, 512, 513):
         got = run(grid)
         assert np.array_equal(got, want), f"MCCONV_G2_GRID={grid}: rms {rms(got - want):.3e}"
+    wide = run(None, wide=True)
+    assert rms(wide - want) <= 1e-7  # (bin 0 is summed in another order there)
+    for grid in (1, 7, 255, 513):
+        got = run(grid, wide=True)
+        assert np.array_equal(got, wide), f"MCCONV_G2_WIDE=1 MCCONV_G2_GRID={grid}: rms {rms(got - wide):.3e}"
 
 
 def test_pinned_host_batches_overlap_copies_and_match(oracle_mod, gpu_lib):
