@@ -526,13 +526,11 @@ __global__ __launch_bounds__(256) void k_mac_resident(const float4* __restrict__
 // HALF: spectra and delay line are read as scaled half4 (8 B per entry, half the bytes), products and sums
 // stay fp32; `inv` = 1 / (scale of IR 0 * FDL scale), 1 / (scale of IR 1 * FDL scale) undoes the scaling.
 template <bool UNIFORM, int NT, bool HALF>
-__global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v, const void* __restrict__ H1v,
-                                                   int pstride_ir, int p_begin, int p_end, int chunk,
-                                                   const void* __restrict__ fdlv, const float4* __restrict__ slotgain,
-                                                   int ring, int slot0, float4* __restrict__ part, int nsum, int ch_off,
-                                                   float4 ugain, float2 inv) {
+__device__ __forceinline__ void mac_stream_body(const int bin, const int ch, const int t, const void* __restrict__ H0v,
+                                                const void* __restrict__ H1v, int pstride_ir, int p_begin, int p_end, int chunk,
+                                                const void* __restrict__ fdlv, const float4* __restrict__ slotgain, int ring,
+                                                int slot0, float4* __restrict__ part, int nsum, int ch_off, float4 ugain, float2 inv) {
     typedef typename std::conditional<HALF, uint2, float4>::type ST;
-    const int bin = blockIdx.x, ch = blockIdx.y, t = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const ST* H0k = reinterpret_cast<const ST*>(H0v) + (size_t)bin * pstride_ir;
     const ST* H1k = reinterpret_cast<const ST*>(H1v) + (size_t)bin * pstride_ir;
@@ -613,6 +611,16 @@ __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v,
         }
         part[((size_t)t * MC_NB + bin) * nsum + ch_off + ch] = o;
     }
+}
+
+template <bool UNIFORM, int NT, bool HALF>
+__global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v, const void* __restrict__ H1v,
+                                                   int pstride_ir, int p_begin, int p_end, int chunk,
+                                                   const void* __restrict__ fdlv, const float4* __restrict__ slotgain,
+                                                   int ring, int slot0, float4* __restrict__ part, int nsum, int ch_off,
+                                                   float4 ugain, float2 inv) {
+    mac_stream_body<UNIFORM, NT, HALF>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, H0v, H1v, pstride_ir, p_begin, p_end, chunk, fdlv,
+                                       slotgain, ring, slot0, part, nsum, ch_off, ugain, inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -1330,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_flush_fix(const double* __restrict__ cr
 // needs the new block, in one workgroup:
 //   wave 0: forward transform of the block (read straight from mapped host
 //           memory), delay-line slot, S/A sums          | waves 1-3: add the chunk partials
-//   all   : p = 0 term  g_v H_{v,.,0} (x) X[t]  for the 256 bins and every voice
+//   all   : p = 0 term  g_v H_{v,.,0} (x) X[t]  and p = 1 term  g_v(t-1) H_{v,.,1} (x) X[t-1]  for the 256 bins and every voice
 //   wave 0: packed inverse transform
 //   all   : overlap-add with the previous tail, Q1/Q2 prefix update, predelay,
 //           Q8, clamp, dry mix, output straight to mapped host memory.
@@ -1343,16 +1351,70 @@ struct VoiceSet {
     const float4* H1[MC_MAXV];
 };
 
-__global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, const float* __restrict__ in2, VoiceSet vset,
-                                               int pstride_ir, float4* __restrict__ fdl, float4* __restrict__ slotgain,
-                                               int ring, int slot0, const float4* __restrict__ part, int nsum,
-                                               const BlockParams* __restrict__ ptab, float* __restrict__ seg, int sr,
-                                               int seg0, float* __restrict__ wet, int wr, double* __restrict__ cring,
-                                               int rc, VoiceSums vs, double inv_n, int compat, int64_t tabs0,
-                                               int64_t predelay, int64_t n_ref, float* __restrict__ outL,
-                                               float* __restrict__ outR, const float2* __restrict__ g_tw, TailDrop td,
-                                               uint2* __restrict__ fdl16, unsigned* __restrict__ done_flag, unsigned seq,
-                                               Retired ret) {
+// Everything one period's tail needs (kernel arguments of k_tail1 and of the fused k_jack).
+struct TailArgs {
+    const float *in1, *in2;  // the period, mapped host memory
+    VoiceSet vset;
+    int pstride_ir;
+    float4 *fdl, *slotgain;
+    int ring, slot0;
+    const float4* part;
+    int nsum;
+    const BlockParams* ptab;
+    float* seg;
+    int sr, seg0;
+    float* wet;
+    int wr;
+    double* cring;
+    int rc;
+    VoiceSums vs;
+    double inv_n;
+    int compat;
+    int64_t tabs0, predelay, n_ref;
+    float *outL, *outR;  // mapped host memory
+    const float2* g_tw;
+    TailDrop td;
+    uint2* fdl16;
+    unsigned* done_flag;  // mapped: the completion word the host spins on
+    unsigned seq;
+    Retired ret;
+    // A tail launched one call ahead parks here until the host rings: *bell == {seq, command 0} go, {seq, 1} give
+    // up without touching any state; after park_ticks (100 MHz) without either it gives up on its own and says so
+    // in *exited.  bell == null: not parked.
+    const unsigned long long* bell;
+    unsigned* exited;
+    unsigned long long park_ticks;
+};
+
+__device__ __forceinline__ void tail1_body(const TailArgs& A) {
+    const float* __restrict__ in1 = A.in1;
+    const float* __restrict__ in2 = A.in2;
+    const VoiceSet& vset = A.vset;
+    const int pstride_ir = A.pstride_ir;
+    float4* __restrict__ fdl = A.fdl;
+    float4* __restrict__ slotgain = A.slotgain;
+    const int ring = A.ring, slot0 = A.slot0;
+    const float4* __restrict__ part = A.part;
+    const int nsum = A.nsum;
+    const BlockParams* __restrict__ ptab = A.ptab;
+    float* __restrict__ seg = A.seg;
+    const int sr = A.sr, seg0 = A.seg0;
+    float* __restrict__ wet = A.wet;
+    const int wr = A.wr;
+    double* __restrict__ cring = A.cring;
+    const int rc = A.rc;
+    const VoiceSums& vs = A.vs;
+    const double inv_n = A.inv_n;
+    const int compat = A.compat;
+    const int64_t tabs0 = A.tabs0, predelay = A.predelay, n_ref = A.n_ref;
+    float* __restrict__ outL = A.outL;
+    float* __restrict__ outR = A.outR;
+    const float2* __restrict__ g_tw = A.g_tw;
+    const TailDrop& td = A.td;
+    uint2* __restrict__ fdl16 = A.fdl16;
+    unsigned* __restrict__ done_flag = A.done_flag;
+    const unsigned seq = A.seq;
+    const Retired& ret = A.ret;
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[FFT_WAVE_LDS];
     __shared__ float4 s_x[MC_NB];  // raw spectra of the new block {X1, X2}
@@ -1370,7 +1432,6 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
     // (PCIe), twiddles, this bin's chunk partials and partition-0 spectra, the previous tail, the delayed wet
     // samples, the Q1/Q2 prefix entries and the retired-epoch residuals.  (The kernel is one workgroup on the
     // critical path of a JACK period: six dependent round trips cost more than everything it computes.)
-    const float xin1 = in1[tid], xin2 = in2[tid];
     const float2 tw0 = g_tw[tid], tw1 = g_tw[tid + 256];
     float4 ysum = make_float4(0.f, 0.f, 0.f, 0.f);
     {
@@ -1384,12 +1445,21 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
         }
     }
     float4 h0v[MC_MAXV], h1v[MC_MAXV];
+    // partition 1 pairs with the previous block: its spectrum and its slot's gains come from the delay line.  The
+    // sweep over partitions >= 2 of THIS block needed nothing of the previous period, so it ran beside that period's
+    // tail on a second stream (mcconv.hip, process_one).
+    float4 h0w[MC_MAXV], h1w[MC_MAXV], g1w[MC_MAXV];
+    const int slot1 = (slot0 + ring - 1) & (ring - 1);
+    const float4 xprev = fdl[(size_t)tid * ring + slot1];
 #pragma unroll
     for (int vi = 0; vi < MC_MAXV; vi++) {  // constant indices: runtime-indexed kernel-argument arrays go to scratch
-        h0v[vi] = h1v[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        h0v[vi] = h1v[vi] = h0w[vi] = h1w[vi] = g1w[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (vi < vset.n) {
             h0v[vi] = vset.H0[vi][(size_t)tid * pstride_ir];
             h1v[vi] = vset.H1[vi][(size_t)tid * pstride_ir];
+            h0w[vi] = vset.H0[vi][(size_t)tid * pstride_ir + 1];
+            h1w[vi] = vset.H1[vi][(size_t)tid * pstride_ir + 1];
+            g1w[vi] = slotgain[(size_t)vset.vid[vi] * ring + slot1];
         }
     }
     const float* prv = seg + (size_t)((seg0 + sr - 1) & (sr - 1)) * 2 * FFT_N;
@@ -1424,6 +1494,36 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
 
     s_tw[tid] = tw0;
     s_tw[tid + 256] = tw1;
+    if (A.bell) {
+        // Parked: everything above was requested without the period; only its 2 KB are still missing.  One lane
+        // polls the mapped doorbell (a PCIe read per poll), the others wait at the barrier.
+        __shared__ int s_go;
+        if (tid == 0) {
+            int go = 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)v == seq) {
+                    go = (v >> 32) == 0;
+                    break;
+                }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {
+                    go = 0;
+                    __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) return;  // nothing has been written: the host launches this period again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the period was written before the doorbell
+    }
+#ifdef MC_JACK_TRACE  // diagnostic build: when the period's work started and ended (100 MHz), next to the completion word
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    const float xin1 = in1[tid], xin2 = in2[tid];
     s_in[0][tid] = xin1;
     s_in[1][tid] = xin2;
     __syncthreads();
@@ -1480,6 +1580,24 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
             y.y += g[0] * a0.y + g[1] * a1.y;
             y.z += g[2] * a2.x + g[3] * a3.x;
             y.w += g[2] * a2.y + g[3] * a3.y;
+            // partition 1 against the previous block, with the gains that block carries
+            const float4 p0 = h0w[vi], p1 = h1w[vi], gq = g1w[vi];
+            a0 = a1 = a2 = a3 = make_float2(0.f, 0.f);
+            if (k == 0) {
+                cmac<true>(a0, p0.x, p0.y, xprev.x, xprev.y);
+                cmac<true>(a1, p1.x, p1.y, xprev.z, xprev.w);
+                cmac<true>(a2, p0.z, p0.w, xprev.x, xprev.y);
+                cmac<true>(a3, p1.z, p1.w, xprev.z, xprev.w);
+            } else {
+                cmac<false>(a0, p0.x, p0.y, xprev.x, xprev.y);
+                cmac<false>(a1, p1.x, p1.y, xprev.z, xprev.w);
+                cmac<false>(a2, p0.z, p0.w, xprev.x, xprev.y);
+                cmac<false>(a3, p1.z, p1.w, xprev.z, xprev.w);
+            }
+            y.x += gq.x * a0.x + gq.y * a1.x;
+            y.y += gq.x * a0.y + gq.y * a1.y;
+            y.z += gq.z * a2.x + gq.w * a3.x;
+            y.w += gq.z * a2.y + gq.w * a3.y;
         }
         s_y[k] = y;
     }
@@ -1587,8 +1705,40 @@ __global__ __launch_bounds__(256) void k_tail1(const float* __restrict__ in1, co
     // (__syncthreads waits vmcnt(0)), then ONE lane issues the system-scope release and the sequence number
     __syncthreads();
     if (tid == 0) {
+#ifdef MC_JACK_TRACE
+        reinterpret_cast<unsigned long long*>(done_flag)[1] = t_start;
+        reinterpret_cast<unsigned long long*>(done_flag)[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tail1(TailArgs A) { tail1_body(A); }
+
+// The tail of period t (workgroup 0, usually parked on its doorbell) and the streaming sweep over partitions >= 2 of
+// period t + 1 (the other 256 bins x chunks workgroups, one voice) in ONE launch: the sweep pairs only with blocks at
+// least two periods old, so it needs nothing the tail produces and runs while the tail waits for the period.
+struct SweepArgs {
+    const void *H0, *H1;
+    int pstride_ir, p_begin, p_end, chunk;
+    const void* fdl;
+    const float4* slotgain;
+    int ring, slot0;
+    float4* part;
+    int nsum, ch_off;
+    float4 ugain;
+    float2 inv;
+    int nchunk;
+};
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_jack(TailArgs A, SweepArgs S) {
+    if (blockIdx.x == 0) {
+        tail1_body(A);
+    } else {
+        const int w = (int)blockIdx.x - 1;
+        mac_stream_body<UNIFORM, 256, false>(w & (MC_NB - 1), w >> 8, 0, S.H0, S.H1, S.pstride_ir, S.p_begin, S.p_end, S.chunk, S.fdl,
+                                             S.slotgain, S.ring, S.slot0, S.part, S.nsum, S.ch_off, S.ugain, S.inv);
     }
 }
 

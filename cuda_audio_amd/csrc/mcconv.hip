@@ -73,6 +73,52 @@ struct IrEntry {
 
 }  // namespace
 
+struct BatchCtx {
+    int T = 0;
+    uint64_t t0 = 0;
+    int pstride = 1;
+    uint64_t predelay = 0;
+    VoiceSums vs;
+    int vir[2][MC_MAXV];  // IR index per half and voice (-1 = none)
+    int slot = 0;
+    int first = 0, count = 0;  // output blocks this engine finishes (the whole batch unless block-sliced)
+    int need_a0 = 0, need_a1 = 0, need_b0 = 0;  // blocks the front half transformed: [a0, a1) and [b0, T)
+    uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
+    bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
+};
+
+// One voice as the MAC sees it
+struct ActiveVoice {
+    int v;                 // gain-table row
+    const IrEntry *ir0, *ir1;
+    int p_end;             // partitions to sweep (multiple of 16), before sharding
+    bool uniform;          // every slot of the window carries the same gains
+    float4 ugain;
+};
+
+// Sample the parameters, advance the cross-fade, stage the per-block table of a
+// batch of T blocks starting at block t_front, and describe the batch in `ctx`.
+struct Staged {
+    BatchCtx ctx;
+    BlockParams* d_ptab;
+    float4* d_sums;
+    BlockParams first;  // host copy of the first block's parameters
+    ActiveVoice act[MC_MAXV];
+    int nact = 0;
+};
+
+
+// JACK path: a period launched one call ahead, parked on its doorbell (process_one)
+struct JackPre {
+    bool valid = false;
+    uint64_t block = 0;   // the block it will finish
+    unsigned seq = 0;     // its doorbell / completion value
+    mc_cc_value cc[2];    // the parameters it was staged with
+    Staged st;
+    bool carries_sweep = false;  // its kernel also runs the sweep of block + 1 ...
+    int carried_vir[2];          // ... for this IR pair
+};
+
 struct mc_engine {
     mc_config cfg;
     int device = 0;
@@ -158,19 +204,8 @@ struct mc_engine {
     uint64_t t_front = 0;  // blocks whose front half (FFT, MAC, inverse, overlap-add) has been issued
     // up to kPipe batches may sit between their front and back halves (sharded
     // operation overlaps the cross-GPU reduce of batch k with the MAC of batch k+1)
-    struct BatchCtx {
-        int T = 0;
-        uint64_t t0 = 0;
-        int pstride = 1;
-        uint64_t predelay = 0;
-        VoiceSums vs;
-        int vir[2][MC_MAXV];  // IR index per half and voice (-1 = none)
-        int slot = 0;
-        int first = 0, count = 0;  // output blocks this engine finishes (the whole batch unless block-sliced)
-        int need_a0 = 0, need_a1 = 0, need_b0 = 0;  // blocks the front half transformed: [a0, a1) and [b0, T)
-        uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
-        bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
-    } pipe[2];
+    typedef ::BatchCtx BatchCtx;
+    BatchCtx pipe[2];
     int pipe_head = 0, pipe_count = 0;
     uint64_t batch_seq = 0;
     // speculative MAC of the next single block (partitions >= 1 do not depend on the next input)
@@ -179,6 +214,19 @@ struct mc_engine {
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
+    float4* d_part_jack[2] = {nullptr, nullptr};  // JACK path: the sweep's partials, double-buffered by block parity
+    JackPre pre;                     // the period parked one call ahead
+    bool park = true;                // MCCONV_NO_PARK=1: every period launched when it arrives
+    unsigned long long park_ticks = 10000000ull;  // a parked tail gives up after this many 100 MHz ticks (100 ms; MCCONV_PARK_MS)
+    unsigned long long* h_bell = nullptr;         // mapped: {sequence number, command} the parked tail polls
+    unsigned long long* hd_bell = nullptr;
+    unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
+    unsigned* hd_exited = nullptr;
+#ifdef MC_JACK_TRACE
+    double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0;
+    unsigned long long tr_prev_end = 0;
+    long tr_n = 0;
+#endif
     bool fft2 = true;     // long batches: second-level transform along the block axis instead of the MAC
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
@@ -216,8 +264,28 @@ void host_twiddles(std::vector<float2>& tw) {
     }
 }
 
+void ring_bell(mc_engine* e, unsigned seq, unsigned command) {
+    // the period (h_io) was written before: release order makes it visible to the tail that acquires the doorbell
+    __atomic_store_n(e->h_bell, ((unsigned long long)command << 32) | seq, __ATOMIC_RELEASE);
+}
+
+// JACK path: a period launched ahead is parked on the engine's stream (process_one).  Before anything else may use the
+// stream, or change what the parked tail has already loaded, it is told to give up.  It has written nothing; the next
+// mc_process launches that period again.
+void unpark(mc_engine* e) {
+    if (e->pre.valid) {
+        ring_bell(e, e->pre.seq, 1);
+        e->pre.valid = false;
+    }
+}
+int leave_jack_path(mc_engine* e) {
+    unpark(e);
+    return MC_OK;
+}
+
 int drain_kernel_events(mc_engine* e) {
     if (!e->kev_n) return MC_OK;
+    unpark(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < e->kev_n; i++) {
         float ms = 0.f;
@@ -248,6 +316,10 @@ int fence_post(mc_engine* e) {
 }
 
 int zero_state(mc_engine* e) {
+    {
+        int rc = leave_jack_path(e);
+        if (rc) return rc;
+    }
     {
         int rc = drain_post(e);
         if (rc) return rc;
@@ -493,26 +565,6 @@ int build_params(mc_engine* e, int T, mc_cc_value (&cc)[2], BlockParams** out_ta
     return all_same ? 0 : 1;
 }
 
-// One voice as the MAC sees it
-struct ActiveVoice {
-    int v;                 // gain-table row
-    const IrEntry *ir0, *ir1;
-    int p_end;             // partitions to sweep (multiple of 16), before sharding
-    bool uniform;          // every slot of the window carries the same gains
-    float4 ugain;
-};
-
-// Sample the parameters, advance the cross-fade, stage the per-block table of a
-// batch of T blocks starting at block t_front, and describe the batch in `ctx`.
-struct Staged {
-    mc_engine::BatchCtx ctx;
-    BlockParams* d_ptab;
-    float4* d_sums;
-    BlockParams first;  // host copy of the first block's parameters
-    ActiveVoice act[MC_MAXV];
-    int nact = 0;
-};
-
 const IrEntry* any_ir(const mc_engine* e) {
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_H) return &e->irs[i];
@@ -644,6 +696,7 @@ void partition_range(const mc_engine* e, int p_hi, int* p_begin, int* p_end) {
 void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, int T, int slot0, int nsum, int ch_off,
                        float4* dst = nullptr) {
     if (!dst) dst = e->d_part;
+    const hipStream_t st = e->stream;
     const int nt = e->stream_nt;
     const int span = p_hi - p_lo;
     const int chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
@@ -655,7 +708,7 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
     const void* fd = half ? (const void*)e->d_fdl16 : (const void*)e->d_fdl;
     const float2 inv = make_float2(1.0f / (a.ir0->scale16 * FDL16_SCALE), 1.0f / (a.ir1->scale16 * FDL16_SCALE));
 #define MC_LAUNCH_STREAM(U, NT, H)                                                                                        \
-    hipLaunchKernelGGL((k_mac_stream<U, NT, H>), grid, dim3(NT), 0, e->stream, h0, h1, e->Pstride, p_lo, p_hi, chunk, fd, sg, \
+    hipLaunchKernelGGL((k_mac_stream<U, NT, H>), grid, dim3(NT), 0, st, h0, h1, e->Pstride, p_lo, p_hi, chunk, fd, sg, \
                        e->ring, slot0, dst, nsum, ch_off, a.ugain, inv)
 #define MC_LAUNCH_STREAM_H(U, NT) \
     do {                          \
@@ -1003,6 +1056,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
     if (e->sliced) return fail(MC_ERR_STATE, "predelay change / voice merge on a block-sliced engine (mc_reset first)");
     {
         int rc = drain_post(e);  // the rings below are rewritten
+        if (!rc) rc = leave_jack_path(e);
         if (rc) return rc;
     }
     const uint64_t b0 = e->t_front, bs = e->epoch_b0, d_old = e->cur_delay;
@@ -1070,6 +1124,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
     if (e->pipe_count >= kPipe) return fail(MC_ERR_STATE, "%d batches already await mc_finish_batch_device", kPipe);
     if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
+    {
+        int rc = leave_jack_path(e);
+        if (rc) return rc;
+    }
     const bool slice = !(first == 0 && count == T);
     if (first < 0 || count <= 0 || first + count > T) return fail(MC_ERR_ARG, "slice [%d, %d) outside the batch of %d", first, first + count, T);
     if (slice && lin) return fail(MC_ERR_ARG, "a partition shard cannot be block-sliced");
@@ -1256,20 +1314,47 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
     return MC_OK;
 }
 
+
+// One JACK period with host buffers (Convolution::onProcess, conv.cu:287-466):
+// zero-copy I/O through mapped pinned memory, the streaming MAC over partitions
+// >= 1 (independent of the new block) and the fused k_tail1.
+// The cross-fade has converged and nothing is ramping: staging the next block's parameters now or at the next call
+// gives the same table entry (what lets a period be launched one call ahead, see process_one)
+bool params_steady(const mc_engine* e, const mc_cc_value (&cc)[2]) {
+    for (int i = 0; i < 2; i++) {
+        if (cc[i].vsteps != 0) return false;
+        bool have = false;
+        for (int v = 0; v < MC_MAXV; v++) {
+            const mc_engine::VoiceSlot& s = e->voice[i][v];
+            if (s.ir < 0) continue;
+            if (s.ir == (int)cc[i].select) {
+                if (s.coef != (double)cc[i].wet) return false;
+                have = true;
+            } else if (s.coef != 0.0) {
+                return false;
+            }
+        }
+        if (!have) return false;
+    }
+    return true;
+}
+
 // The output of the period is on the host once its last kernel has published the sequence number: spin on the
 // mapped word (a JACK callback blocks here anyway; the reference blocks in cudaEventSynchronize, conv.cu:455);
-// fall back to a stream sync if it does not arrive in time.
-int wait_period(mc_engine* e) {
+// fall back to a stream sync if it does not arrive in time.  Returns 1 when a parked tail says it gave up on its own.
+int wait_period(mc_engine* e, unsigned seq) {
     if (!e->spin_wait) {
         HIP_TRY(hipEventSynchronize(e->ev_tail));
         return MC_OK;
     }
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) {
-        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+    while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != seq) {
+        if (__atomic_load_n(e->h_exited, __ATOMIC_ACQUIRE) == seq) return 1;
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(300)) {
+            unpark(e);  // (a kernel parked for the NEXT period would hold the stream until its own timeout)
             HIP_TRY(hipStreamSynchronize(e->stream));
-            if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != e->flag_seq) return fail(MC_ERR_HIP, "period did not complete");
+            if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != seq) return fail(MC_ERR_HIP, "period did not complete");
             break;
         }
         __builtin_ia32_pause();
@@ -1277,133 +1362,323 @@ int wait_period(mc_engine* e) {
     return MC_OK;
 }
 
-// One JACK period with host buffers (Convolution::onProcess, conv.cu:287-466):
-// zero-copy I/O through mapped pinned memory, the streaming MAC over partitions
-// >= 1 (independent of the new block) and the fused k_tail1.
+// One JACK period with host buffers (Convolution::onProcess, conv.cu:287-466): zero-copy I/O through mapped pinned
+// memory, the streaming MAC over the partitions that do not depend on the new block, and the fused k_tail1.
+//
+// Who sums what.  An engine that owns the IR's first partitions (every engine but a partition shard with
+// part_begin > 0): the tail takes partition 0 (the new block) and partition 1 (the previous block, from the delay
+// line); the streaming sweep takes partitions >= 2 - they pair with blocks at least two periods old, so the sweep of
+// period t + 1 depends on nothing period t produces.  A shard that starts later sweeps its whole range.
+//
+// Launching a period ahead.  Measured (MC_JACK_TRACE build, profiles/r2_jack_trace.md): of 16 us per back-to-back call
+// the tail kernel works 6.5 us; the rest is the host's launch call and the dispatch latency that follow the arrival of
+// the period.  So, in the steady state, call t launches - behind the tail of period t - ONE kernel (k_jack) whose
+// workgroup 0 is the tail of period t + 1 and whose other workgroups are the sweep of period t + 2.  The tail requests
+// everything it needs except the period itself and parks on a doorbell in mapped memory; call t + 1 copies the period
+// in, rings, and waits for the completion word: no launch on the critical path.  The parameters a parked period was
+// staged with are compared with the ones the next call samples; any difference (a controller moved, an IR was
+// selected) tells it to give up - it has written nothing - and the period is launched the ordinary way.  A parked
+// tail that hears nothing for 100 ms gives up on its own (a host that stopped calling must not leave a kernel behind).
 int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
-    {
-        int rc = drain_post(e);
-        if (rc) return rc;
-    }
+#ifdef MC_JACK_TRACE
+    const auto tr0 = std::chrono::steady_clock::now();
+#endif
     const size_t cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
-    Staged st;
+    mc_cc_value cc[2];
     {
-        mc_cc_value cc[2];
         int rc = sample_params(e, cc);
-        if (!rc) rc = retire_epoch(e, cc[0].predelay);
-        if (!rc) rc = stage_params(e, 1, cc, &st);
         if (rc) return rc;
     }
-    const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
-    const int seg0 = (int)(e->t_front & (uint64_t)(e->sr - 1));
 
-    // voices with partitions >= 1 to sweep, and voices with a partition-0 term
-    ActiveVoice sweep[MC_MAXV];
-    int lo[MC_MAXV], hi[MC_MAXV], nsweep = 0;
-    VoiceSet vset;
-    std::memset(&vset, 0, sizeof(vset));
-    for (int a = 0; a < st.nact; a++) {
-        int pb, pe;
-        partition_range(e, st.act[a].p_end, &pb, &pe);
-        if (pe <= pb) continue;
-        if (pb == 0) {
-            vset.vid[vset.n] = st.act[a].v;
-            vset.H0[vset.n] = st.act[a].ir0->d_H;
-            vset.H1[vset.n] = st.act[a].ir1->d_H;
-            vset.n++;
+    // ---- the voices and ranges of a staged block
+    struct Plan {
+        ActiveVoice sweep[MC_MAXV];
+        int lo[MC_MAXV], hi[MC_MAXV], nsweep = 0, nsum = 1;
+        VoiceSet vset;
+    };
+    auto make_plan = [&](const Staged& st, Plan& pl) {
+        std::memset(&pl.vset, 0, sizeof(pl.vset));
+        pl.nsweep = 0;
+        for (int a = 0; a < st.nact; a++) {
+            int pb, pe;
+            partition_range(e, st.act[a].p_end, &pb, &pe);
+            if (pe <= pb) continue;
+            if (pb == 0) {
+                pl.vset.vid[pl.vset.n] = st.act[a].v;
+                pl.vset.H0[pl.vset.n] = st.act[a].ir0->d_H;
+                pl.vset.H1[pl.vset.n] = st.act[a].ir1->d_H;
+                pl.vset.n++;
+            }
+            const int first = pb == 0 ? 2 : pb;
+            if (pe > first) {
+                pl.sweep[pl.nsweep] = st.act[a];
+                pl.lo[pl.nsweep] = first;
+                pl.hi[pl.nsweep] = pe;
+                pl.nsweep++;
+            }
         }
-        if (pe > std::max(pb, 1)) {
-            sweep[nsweep] = st.act[a];
-            lo[nsweep] = std::max(pb, 1);
-            hi[nsweep] = pe;
-            nsweep++;
+        pl.nsum = std::max(1, pl.nsweep) * e->nchunk;
+    };
+    auto sweep_uniform = [&](const ActiveVoice& av, int hi, uint64_t blk) {
+        // one gain for all slots only when the last change is older than every slot of the sweep
+        return e->gain_change_block[av.v] + (uint64_t)hi <= blk && e->gain_change_block[av.v] < blk;
+    };
+    // standalone sweep of block `blk` into its partial buffer (timed: the kernel the latency-mode roofline is quoted on)
+    auto launch_sweep = [&](const Plan& pl, uint64_t blk) -> int {
+        float4* dst = e->d_part_jack[blk & 1];
+        if (!pl.nsweep) {
+            HIP_TRY(hipMemsetAsync(dst, 0, sizeof(float4) * (size_t)MC_NB * pl.nsum, e->stream));
+            return MC_OK;
         }
-    }
-    const int nsum = std::max(1, nsweep) * e->nchunk;
-
-    // timed MAC launches (the kernel the roofline is quoted on); `blk` = the block they belong to
-    auto launch_mac = [&](uint64_t blk) -> int {
-        hipEvent_t *k0 = nullptr, *k1 = nullptr;
         if (e->ktiming) {
             if (e->kev_n == kEvPool) {
                 int rc = drain_kernel_events(e);
                 if (rc) return rc;
             }
-            k0 = &e->kev[e->kev_n][0];
-            k1 = &e->kev[e->kev_n][1];
             e->kev_blocks[e->kev_n] = 1;
-            HIP_TRY(hipEventRecord(*k0, e->stream));
+            HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
         }
-        // partition p of block `blk` pairs with slot (blk - p); p >= 1 only touches blocks < blk
         const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
         int swept = 0;
-        for (int a = 0; a < nsweep; a++) {
-            ActiveVoice av = sweep[a];
-            // one gain for all slots only when the last change is older than every slot of the sweep
-            av.uniform = e->gain_change_block[av.v] + (uint64_t)hi[a] <= blk && e->gain_change_block[av.v] < blk;
-            launch_mac_stream(e, av, lo[a], hi[a], 1, bslot0, nsum, a * e->nchunk);
-            swept = std::max(swept, hi[a] - (lo[a] == 1 ? 0 : lo[a]));
+        for (int a = 0; a < pl.nsweep; a++) {
+            ActiveVoice av = pl.sweep[a];
+            av.uniform = sweep_uniform(av, pl.hi[a], blk);
+            launch_mac_stream(e, av, pl.lo[a], pl.hi[a], 1, bslot0, pl.nsum, a * e->nchunk, dst);
+            swept = std::max(swept, pl.hi[a] - (pl.lo[a] == 2 ? 0 : pl.lo[a]));
         }
         if (e->ktiming) {
-            HIP_TRY(hipEventRecord(*k1, e->stream));
+            HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
             e->kev_n++;
             e->ks.resident = 0;
             e->ks.partitions = (uint32_t)swept;
         }
         return MC_OK;
     };
-    bool spec_hit = e->spec_valid && e->spec_block == e->t_front && e->spec_nact == nsweep;
-    if (spec_hit)
-        for (int a = 0; a < nsweep && spec_hit; a++)
-            spec_hit = e->spec_vir[0][a] == st.ctx.vir[0][sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][sweep[a].v];
-    if (!spec_hit) {
-        if (nsweep) {
-            int rc = launch_mac(e->t_front);
-            if (rc) return rc;
-        } else {
-            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)MC_NB * nsum, e->stream));
+    auto remember_sweep = [&](const Plan& pl, const Staged& st, uint64_t blk) {
+        e->spec_valid = true;
+        e->spec_block = blk;
+        e->spec_nact = pl.nsweep;
+        for (int a = 0; a < pl.nsweep; a++) {
+            e->spec_vir[0][a] = st.ctx.vir[0][pl.sweep[a].v];
+            e->spec_vir[1][a] = st.ctx.vir[1][pl.sweep[a].v];
         }
+    };
+    auto sweep_matches = [&](const Plan& pl, const Staged& st, uint64_t blk) {
+        bool ok = e->spec_valid && e->spec_block == blk && e->spec_nact == pl.nsweep;
+        for (int a = 0; a < pl.nsweep && ok; a++)
+            ok = e->spec_vir[0][a] == st.ctx.vir[0][pl.sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][pl.sweep[a].v];
+        return ok;
+    };
+    auto tail_args = [&](const Staged& st, const Plan& pl, uint64_t blk, unsigned seq, bool parked) {
+        TailArgs A;
+        std::memset(&A, 0, sizeof(A));
+        A.in1 = e->hd_io + 0 * cap;
+        A.in2 = e->hd_io + 1 * cap;
+        A.vset = pl.vset;
+        A.pstride_ir = e->Pstride;
+        A.fdl = e->d_fdl;
+        A.slotgain = e->d_slotgain;
+        A.ring = e->ring;
+        A.slot0 = (int)(blk & (uint64_t)(e->ring - 1));
+        A.part = e->d_part_jack[blk & 1];
+        A.nsum = pl.nsum;
+        A.ptab = st.d_ptab;
+        A.seg = e->d_seg;
+        A.sr = e->sr;
+        A.seg0 = (int)(blk & (uint64_t)(e->sr - 1));
+        A.wet = e->d_wet;
+        A.wr = e->wr;
+        A.cring = e->d_cring;
+        A.rc = e->rc;
+        A.vs = st.ctx.vs;
+        A.inv_n = 1.0 / (double)e->cfg.n_ref;
+        A.compat = (int)e->cfg.compat;
+        A.tabs0 = (int64_t)blk;
+        A.predelay = (int64_t)st.ctx.predelay;
+        A.n_ref = (int64_t)e->cfg.n_ref;
+        A.outL = e->hd_io + 2 * cap;
+        A.outR = e->hd_io + 3 * cap;
+        A.g_tw = e->d_tw;
+        A.td = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
+        A.fdl16 = e->d_fdl16;
+        A.done_flag = e->hd_flag;
+        A.seq = seq;
+        A.ret = make_retired(e);
+        A.bell = parked ? e->hd_bell : nullptr;
+        A.exited = e->hd_exited;
+        A.park_ticks = e->park_ticks;
+        return A;
+    };
+
+    // ---- this period: a parked tail staged with the same parameters, or the ordinary launch
+    unsigned my_seq = 0;
+    bool relaunch_ok = false;  // (a parked period that gave up on its own can be launched again as it was staged)
+    Staged st_now;
+    Plan pl_now;
+    auto same_cc = [](const mc_cc_value& a, const mc_cc_value& b) {  // (field by field: the struct has padding)
+        return a.select == b.select && a.predelay == b.predelay && a.speed == b.speed && a.vsteps == b.vsteps && a.dry == b.dry &&
+               a.wet == b.wet && a.panDry == b.panDry && a.panWet == b.panWet && a.level == b.level;
+    };
+    const bool hit = e->pre.valid && e->pre.block == e->t_front && same_cc(cc[0], e->pre.cc[0]) && same_cc(cc[1], e->pre.cc[1]) &&
+                     cc[0].predelay == e->cur_delay;
+    if (hit) {
+        my_seq = e->pre.seq;
+        ring_bell(e, my_seq, 0);
+        e->pre.valid = false;
+        st_now = e->pre.st;
+        pl_now = Plan();
+        make_plan(st_now, pl_now);
+        relaunch_ok = true;
+        // the sweep the parked kernel carries is the one the NEXT period will use
+        e->spec_valid = false;
+        if (e->pre.carries_sweep) {
+            e->spec_valid = true;
+            e->spec_block = e->t_front + 1;
+            e->spec_nact = 1;
+            e->spec_vir[0][0] = e->pre.carried_vir[0];
+            e->spec_vir[1][0] = e->pre.carried_vir[1];
+        }
+    } else {
+        unpark(e);
+        {
+            int rc = drain_post(e);
+            if (!rc) rc = retire_epoch(e, cc[0].predelay);
+            if (!rc) rc = stage_params(e, 1, cc, &st_now);
+            if (rc) return rc;
+        }
+        make_plan(st_now, pl_now);
+        if (!sweep_matches(pl_now, st_now, e->t_front)) {
+            int rc = launch_sweep(pl_now, e->t_front);
+            if (rc) return rc;
+        }
+        e->spec_valid = false;
+        my_seq = ++e->flag_seq;
+        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front, my_seq, false));
+        HIP_TRY(hipGetLastError());
     }
-    e->spec_valid = false;
-    hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, e->hd_io + 0 * cap, e->hd_io + 1 * cap, vset, e->Pstride,
-                       e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, seg0, e->d_wet, e->wr,
-                       e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,
-                       (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq, make_retired(e));
-    HIP_TRY(hipGetLastError());
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
     e->t_front += 1;
     e->t_abs = e->t_front;
-    if (e->speculate && nsweep) {
-        // In the shadow of the JACK period: the partition sweep of the NEXT block over partitions >= 1
-        // needs only blocks already in the delay line, and every slot carries its own gains, so the
-        // result stays exact under any parameter change except a change of the sounding IR set
-        // (checked above) or an IR reload.
-        int rc = launch_mac(e->t_front);
+
+    // ---- the next period: parked one call ahead when nothing is moving, else only its sweep (as a speculation: every
+    // slot carries its own gains, so it stays exact under any parameter change except a change of the sounding IR set
+    // or an IR reload, which the next call checks)
+    bool parked_next = false;
+    if (e->park && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half && params_steady(e, cc) &&
+        cc[0].predelay == e->cur_delay) {
+        Staged st_next;
+        int rc = stage_params(e, 1, cc, &st_next);  // (steady: advancing the cross-fade by a block changes nothing)
         if (rc) return rc;
-        e->spec_valid = true;
-        e->spec_block = e->t_front;
-        e->spec_nact = nsweep;
-        for (int a = 0; a < nsweep; a++) {
-            e->spec_vir[0][a] = st.ctx.vir[0][sweep[a].v];
-            e->spec_vir[1][a] = st.ctx.vir[1][sweep[a].v];
+        Plan pl_next;
+        make_plan(st_next, pl_next);
+        if (st_next.ctx.pstride == 0 && pl_next.nsweep <= 1 && std::memcmp(&st_next.first, &st_now.first, sizeof(BlockParams)) == 0) {
+            // the sweep of the period about to be parked, unless the kernel ahead of it already carries it
+            if (!sweep_matches(pl_next, st_next, e->t_front)) {
+                rc = launch_sweep(pl_next, e->t_front);
+                if (rc) return rc;
+                remember_sweep(pl_next, st_next, e->t_front);
+            }
+            const unsigned seq = ++e->flag_seq;
+            TailArgs A = tail_args(st_next, pl_next, e->t_front, seq, true);
+            SweepArgs S;
+            std::memset(&S, 0, sizeof(S));
+            const uint64_t blk2 = e->t_front + 1;  // the sweep this kernel carries
+            bool uni = true;
+            if (pl_next.nsweep == 1) {
+                const ActiveVoice& av = pl_next.sweep[0];
+                const int span = pl_next.hi[0] - pl_next.lo[0];
+                uni = sweep_uniform(av, pl_next.hi[0], blk2);
+                S.H0 = av.ir0->d_H;
+                S.H1 = av.ir1->d_H;
+                S.pstride_ir = e->Pstride;
+                S.p_begin = pl_next.lo[0];
+                S.p_end = pl_next.hi[0];
+                S.chunk = round_up(std::max(1, (span + e->nchunk - 1) / e->nchunk), 64);
+                S.fdl = e->d_fdl;
+                S.slotgain = e->d_slotgain + (size_t)av.v * e->ring;
+                S.ring = e->ring;
+                S.slot0 = (int)(blk2 & (uint64_t)(e->ring - 1));
+                S.part = e->d_part_jack[blk2 & 1];
+                S.nsum = pl_next.nsum;
+                S.ch_off = 0;
+                S.ugain = av.ugain;
+                S.inv = make_float2(1.f, 1.f);
+                S.nchunk = e->nchunk;
+            }
+            const dim3 grid(1 + (pl_next.nsweep == 1 ? MC_NB * e->nchunk : 0));
+            if (uni)
+                hipLaunchKernelGGL(k_jack<true>, grid, dim3(256), 0, e->stream, A, S);
+            else
+                hipLaunchKernelGGL(k_jack<false>, grid, dim3(256), 0, e->stream, A, S);
+            HIP_TRY(hipGetLastError());
+            e->pre.valid = true;
+            e->pre.block = e->t_front;
+            e->pre.seq = seq;
+            e->pre.cc[0] = cc[0];
+            e->pre.cc[1] = cc[1];
+            e->pre.st = st_next;
+            e->pre.carries_sweep = pl_next.nsweep == 1;
+            if (pl_next.nsweep == 1) {
+                e->pre.carried_vir[0] = st_next.ctx.vir[0][pl_next.sweep[0].v];
+                e->pre.carried_vir[1] = st_next.ctx.vir[1][pl_next.sweep[0].v];
+            }
+            parked_next = true;
         }
     }
-    // the output of THIS block is on the host once k_tail1 has published its sequence number; the speculative
-    // sweep keeps running.  Spin on the mapped word (a JACK callback blocks here anyway; the reference blocks in
-    // cudaEventSynchronize, conv.cu:455); fall back to a stream sync if it does not arrive in time.
-    {
-        int rc = wait_period(e);
-        if (rc) return rc;
+    if (!parked_next && e->speculate) {
+        // (not steady, or more than one voice sounding: the next period's sweep alone, in the shadow of this period)
+        Staged& st = st_now;
+        Plan& pl = pl_now;
+        if (pl.nsweep && !(e->spec_valid && e->spec_block == e->t_front)) {
+            int rc = launch_sweep(pl, e->t_front);
+            if (rc) return rc;
+            remember_sweep(pl, st, e->t_front);
+        }
     }
+#ifdef MC_JACK_TRACE
+    const auto tr1 = std::chrono::steady_clock::now();
+#endif
+    // the output of THIS block is on the host once its tail has published its sequence number.  Spin on the mapped word
+    // (a JACK callback blocks here anyway; the reference blocks in cudaEventSynchronize, conv.cu:455).
+    for (;;) {
+        int rc = wait_period(e, my_seq);
+        if (rc == MC_OK) break;
+        if (rc != 1) return rc;
+        // the parked tail gave up on its own (the host was away for more than park_ms): the same period, launched the
+        // ordinary way behind whatever is queued
+        if (!relaunch_ok) return fail(MC_ERR_HIP, "period did not complete");
+        relaunch_ok = false;
+        unpark(e);  // (the kernel parked for the period after this one must not run before it)
+        my_seq = ++e->flag_seq;
+        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front - 1, my_seq, false));
+        HIP_TRY(hipGetLastError());
+    }
+#ifdef MC_JACK_TRACE
+    const auto tr2 = std::chrono::steady_clock::now();
+#endif
     std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
     std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * MC_B);
+#ifdef MC_JACK_TRACE
+    {
+        const auto tr3 = std::chrono::steady_clock::now();
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(e->h_flag);
+        if (e->tr_n >= 100) {  // (skip the warm-up)
+            e->tr_launch += std::chrono::duration<double, std::micro>(tr1 - tr0).count();
+            e->tr_flag += std::chrono::duration<double, std::micro>(tr2 - tr0).count();
+            e->tr_total += std::chrono::duration<double, std::micro>(tr3 - tr0).count();
+            e->tr_kernel += (double)(w[2] - w[1]) * 0.01;
+            if (e->tr_prev_end) e->tr_gap += (double)(w[1] - e->tr_prev_end) * 0.01;
+        }
+        e->tr_prev_end = w[2];
+        e->tr_n++;
+    }
+#endif
     return MC_OK;
 }
 
@@ -1518,7 +1793,7 @@ int process_period(mc_engine* e, const float* in1, const float* in2, float* outL
     e->pipelined = was_piped;
     if (rc) return rc;
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
-    rc = wait_period(e);
+    rc = wait_period(e, e->flag_seq);
     if (rc) return rc;
     std::memcpy(outL, e->h_io + 2 * cap, bytes);
     std::memcpy(outR, e->h_io + 3 * cap, bytes);
@@ -1533,6 +1808,10 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
     {
         int rc = drain_post(e);
+        if (rc) return rc;
+    }
+    {
+        int rc = leave_jack_path(e);
         if (rc) return rc;
     }
     const int pm = e->pm;
@@ -1637,7 +1916,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         }
     }
     {
-        int rc = wait_period(e);
+        int rc = wait_period(e, e->flag_seq);
         if (rc) return rc;
     }
     std::memcpy(outL, e->h_io + 2 * cap, bytes);
@@ -1782,9 +2061,15 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Thost * MC_B));
     ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
-    ENG_TRY(hipHostMalloc(&e->h_flag, 64, hipHostMallocMapped));
+    ENG_TRY(hipHostMalloc(&e->h_flag, 256, hipHostMallocMapped));  // completion word, doorbell, "gave up" word: a line each
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
-    *e->h_flag = 0;
+    std::memset(e->h_flag, 0, 256);
+    e->h_bell = reinterpret_cast<unsigned long long*>(e->h_flag + 16);
+    e->hd_bell = reinterpret_cast<unsigned long long*>(e->hd_flag + 16);
+    e->h_exited = e->h_flag + 32;
+    e->hd_exited = e->hd_flag + 32;
+    if (std::getenv("MCCONV_NO_PARK")) e->park = false;
+    if (const char* pm = std::getenv("MCCONV_PARK_MS")) e->park_ticks = (unsigned long long)std::max(1, std::atoi(pm)) * 100000ull;
     ENG_TRY(hipMalloc(&e->d_done_ctr, sizeof(unsigned)));
     ENG_TRY(hipMemset(e->d_done_ctr, 0, sizeof(unsigned)));
     if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
@@ -1793,6 +2078,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         ENG_TRY(hipEventCreateWithFlags(&e->ptab_ev[i], hipEventDisableTiming));
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) ENG_TRY(hipMalloc(&e->d_part_jack[i], sizeof(float4) * (size_t)MC_NB * e->nchunk * MC_MAXV));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
@@ -1829,7 +2115,15 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
 
 void mc_destroy(mc_engine* e) {
     if (!e) return;
+#ifdef MC_JACK_TRACE
+    if (e->tr_n > 100) {
+        const double n = (double)(e->tr_n - 100);
+        fprintf(stderr, "mcconv JACK trace over %ld periods (us): entry -> launches issued %.2f, -> flag seen %.2f, -> return %.2f; k_tail1 start -> end %.2f, "
+                        "end of the previous k_tail1 -> start of this one %.2f\n", e->tr_n - 100, e->tr_launch / n, e->tr_flag / n, e->tr_total / n, e->tr_kernel / n, e->tr_gap / n);
+    }
+#endif
     (void)hipSetDevice(e->device);
+    unpark(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
@@ -1893,6 +2187,8 @@ void mc_destroy(mc_engine* e) {
         }
     }
     if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
+    (void)hipFree(e->d_part_jack[0]);
+    (void)hipFree(e->d_part_jack[1]);
     if (e->kev_created)
         for (int i = 0; i < kEvPool; i++) {
             (void)hipEventDestroy(e->kev[i][0]);
@@ -1932,6 +2228,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     IrEntry& ir = e->irs[idx];
     {
         int rc = drain_post(e);
+        if (!rc) rc = leave_jack_path(e);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2120,6 +2417,7 @@ int mc_sync(mc_engine* e) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
     int rc = drain_post(e);
+    if (!rc) rc = leave_jack_path(e);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     return MC_OK;
@@ -2145,6 +2443,7 @@ int mc_set_stream(mc_engine* e, void* s) {
     HIP_TRY(hipSetDevice(e->device));
     {
         int rc = drain_post(e);
+        if (!rc) rc = leave_jack_path(e);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2253,6 +2552,10 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         default: return fail(MC_ERR_ARG, "unknown buffer %d", which);
     }
     if (off + bytes > cap) return fail(MC_ERR_ARG, "read beyond buffer (%llu + %llu > %llu)", (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)cap);
+    {
+        int rc = leave_jack_path(e);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(dst, src + off, bytes, hipMemcpyDeviceToHost));
     return MC_OK;
