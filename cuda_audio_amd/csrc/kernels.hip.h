@@ -2493,18 +2493,10 @@ __device__ __forceinline__ void g2_tables(float2* t_lo, float2* t_hi) {  // w = 
 }
 
 // two consecutive radix-4 stages (quarter lengths 4 Q and Q) on the 16 elements pos0 + Q m of a thread; see f2_pair
+// the two radix-4 stages of a pass on a thread's 16 elements, in registers (a[m] = element pos0 + Q m)
 template <bool INV, int LQ>
-__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0) {
-    constexpr int Q = 1 << LQ;
-    constexpr int stride = Q >= 32 ? Q + Q / 32 : Q;  // elements Q apart: whole pad groups apart, or inside one (see f2_pair)
+__device__ __forceinline__ void g2_pair_core(v2f (&a)[16], const float2* t_lo, const float2* t_hi, int j0) {
     constexpr int step1 = G2_N >> (LQ + 4), step2 = G2_N >> (LQ + 2);
-    // the LDS address is recomputed in every pass: shared between the forward and the inverse transform it would stay
-    // live across the whole kernel and spill
-    asm volatile("" : "+v"(pos0), "+v"(j0));
-    float2* p = s + G2_P(pos0);
-    v2f a[16];
-#pragma unroll
-    for (int m = 0; m < 16; m++) a[m] = vx_ld(p + stride * m);
     const v2f wa = vg_tw(t_lo, t_hi, j0 * step1), w = vg_tw(t_lo, t_hi, j0 * step2);
     const v2f wr[4] = {wa, vx_mul(wa, W16_1), vx_mul(wa, W16_2), vx_mul(wa, W16_3)};
     if (!INV) {
@@ -2530,8 +2522,32 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
             vx_bfly4<true>(a[r], a[r + 4], a[r + 8], a[r + 12]);
         }
     }
+}
+// LOAD / STORE = false: the elements come from / stay in the caller's registers (k_g2_mac: the first forward pass takes
+// the window rows a thread has just loaded - they ARE its elements tt + 512 m - and the last inverse pass leaves the
+// outputs with the thread that stores them: two trips through LDS and two barriers less per sequence)
+template <bool INV, int LQ, bool LOAD = true, bool STORE = true>
+__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0, v2f (&a)[16]) {
+    constexpr int Q = 1 << LQ;
+    constexpr int stride = Q >= 32 ? Q + Q / 32 : Q;  // elements Q apart: whole pad groups apart, or inside one (see f2_pair)
+    // the LDS address is recomputed in every pass: shared between the forward and the inverse transform it would stay
+    // live across the whole kernel and spill
+    asm volatile("" : "+v"(pos0), "+v"(j0));
+    float2* p = s + G2_P(pos0);
+    if (LOAD) {
 #pragma unroll
-    for (int m = 0; m < 16; m++) vx_st(p + stride * m, a[m]);
+        for (int m = 0; m < 16; m++) a[m] = vx_ld(p + stride * m);
+    }
+    g2_pair_core<INV, LQ>(a, t_lo, t_hi, j0);
+    if (STORE) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) vx_st(p + stride * m, a[m]);
+    }
+}
+template <bool INV, int LQ>
+__device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const float2* t_hi, int pos0, int j0) {
+    v2f a[16];
+    g2_pair<INV, LQ, true, true>(s, t_lo, t_hi, pos0, j0, a);
 }
 
 // the radix-2 stage on adjacent pairs (its own inverse up to the factor 2): eight pairs per thread
@@ -2824,6 +2840,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
     __shared__ float2 t_lo[128], t_hi[64];
     const int nch = nitems >> 8;
     g2_tables(t_lo, t_hi);
+    __syncthreads();  // the first forward pass runs on registers: nothing else orders its twiddle reads after the tables
 #if G2_STAMPS  // diagnostic build only: where a workgroup's time goes (s_memtime ticks = shader cycles)
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_now;
     int st_items = 0;
@@ -2846,17 +2863,21 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
         const int bin = (xq / nch) * 8 + (item & 7), chunk = xq % nch;
         const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
         const float4* fk = fdl + (size_t)bin * ring;
+#ifdef G2_ALIAS_TEST  // timing only (wrong data): every bin's window starts 1 KB further - does the 1 MB bin stride alias in HBM?
+        const int sb = slot0 + t_c0 - (taps - 1) + 64 * bin;
+#else
         const int sb = slot0 + t_c0 - (taps - 1);
+#endif
         for (int pass = 0; pass < (bin == 0 ? 2 : 1); pass++) {
             const float cj = pass ? -1.0f : 1.0f;  // second run of bin 0: conj(z)
             const int row = pass ? 256 : bin;
             int tt = threadIdx.x;
             asm volatile("" : "+v"(tt));
             G2_STAMP(-1);
-            // ---- window: 16 bytes per slot carry both inputs; x1 to LDS, x2 waits in registers
-            v2f x2[ROWS];
+            // ---- window: 16 bytes per slot carry both inputs.  The rows a thread loads, n = tt + 512 r, are exactly its 16
+            // elements of the first forward pass: that pass runs on the registers (x1 at once, x2 when the buffer is free)
+            v2f x1[ROWS], x2[ROWS];
             {
-                float2* w0 = &s[G2_P(tt)];
 #pragma unroll
                 for (int r0 = 0; r0 < ROWS; r0 += G2B_FILL) {
                     float4 x[G2B_FILL];
@@ -2868,14 +2889,18 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
                     }
 #pragma unroll
                     for (int r = 0; r < G2B_FILL; r++) {
-                        vx_st(w0 + (r0 + r) * WS, v2f{x[r].x, cj * x[r].y});
+                        x1[r0 + r] = v2f{x[r].x, cj * x[r].y};
                         x2[r0 + r] = v2f{x[r].z, cj * x[r].w};
                     }
                 }
             }
-            __syncthreads();
             G2_STAMP(0);
-            g2_forward<false>(s, t_lo, t_hi, tt);
+            g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x1);  // quarter lengths 2048, 512
+            __syncthreads();
+            g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);  // 128, 32
+            __syncthreads();
+            g2_pair<false, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);  // 8, 2
+            __syncthreads();
             G2_STAMP(1);
             // ---- own entries of X1 (pairs 2 j, 2 j + 1, j = tt + 512 r; the radix-2 stage on the way) to registers
             v2f X1[ROWS];
@@ -2889,16 +2914,14 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
                     X1[2 * r + 1] = a - b;
                 }
             }
-            __syncthreads();
-            {
-                asm volatile("" : "+v"(tt));
-                float2* w0 = &s[G2_P(tt)];
-#pragma unroll
-                for (int r = 0; r < ROWS; r++) vx_st(w0 + r * WS, x2[r]);
-            }
-            __syncthreads();
+            __syncthreads();  // every thread has its X1 entries: the buffer is free for x2
             G2_STAMP(2);
-            g2_forward<false>(s, t_lo, t_hi, tt);
+            g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x2);
+            __syncthreads();
+            g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+            __syncthreads();
+            g2_pair<false, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
+            __syncthreads();
             G2_STAMP(3);
             // ---- products: Y_c = sum_voices g (X1 H1c + X2 H2c) on the thread's own entries; Y_L replaces X2 in LDS,
             // Y_R replaces X1 in registers.  The first voice's spectra run G2B_AHEAD entry pairs ahead of the arithmetic
@@ -2957,17 +2980,14 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             }
             __syncthreads();
             G2_STAMP(4);
-            g2_inverse<false>(s, t_lo, t_hi, tt);
-            G2_STAMP(5);
-            // ---- the valid part of the circle (its first taps - 1 outputs are discarded) of Y_L to registers
+            // ---- inverse of Y_L; its last pass leaves element tt + 512 m = output block tt + 512 m - (taps - 1) in registers
             v2f yl[ROWS];
-            {
-                asm volatile("" : "+v"(tt));
-                const float2* q0 = &s[G2_P(tt + taps - 1)];
-#pragma unroll
-                for (int k = 0; k < ROWS; k++)
-                    if (tt + G2B_THREADS * k < nout) yl[k] = vx_ld(q0 + k * WS);
-            }
+            g2_pair<true, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
+            __syncthreads();
+            g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+            __syncthreads();
+            g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yl);
+            G2_STAMP(5);
             __syncthreads();
             {
                 asm volatile("" : "+v"(tt));
@@ -2980,19 +3000,23 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             }
             __syncthreads();
             G2_STAMP(6);
-            g2_inverse<false>(s, t_lo, t_hi, tt);
-            G2_STAMP(7);
             {
+                v2f yr[ROWS];
+                g2_pair<true, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
+                __syncthreads();
+                g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+                __syncthreads();
+                g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yr);
+                G2_STAMP(7);
+                // the valid part of the circle: its first taps - 1 outputs are discarded
                 asm volatile("" : "+v"(tt));
                 const float sc = 1.0f / (float)G2_N;
-                const float2* q0 = &s[G2_P(tt + taps - 1)];
                 float4* dst = Yc + (size_t)bin * ycap + t_c0;
 #pragma unroll
-                for (int k = 0; k < ROWS; k++) {
-                    const int t = tt + G2B_THREADS * k;
-                    if (t < nout) {
-                        const v2f yr = vx_ld(q0 + k * WS);
-                        float4 y = make_float4(yl[k].x * sc, yl[k].y * sc, yr.x * sc, yr.y * sc);  // (second run of bin 0: h2 * conj z)
+                for (int m = 0; m < ROWS; m++) {
+                    const int t = tt + G2B_THREADS * m - (taps - 1);
+                    if (t >= 0 && t < nout) {
+                        float4 y = make_float4(yl[m].x * sc, yl[m].y * sc, yr[m].x * sc, yr[m].y * sc);  // (second run of bin 0: h2 * conj z)
                         if (pass) {
                             const float4 o = dst[t];
                             y = make_float4(o.x + y.x, o.y + y.y, o.z + y.z, o.w + y.w);
@@ -3009,7 +3033,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
         }
     }
 #if G2_STAMPS
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137 || blockIdx.x == 300 || blockIdx.x == 511))
+    if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 137 || blockIdx.x == 300 || blockIdx.x == 700 || blockIdx.x == 1100))
         printf("g2 wg %d items %d: fill %llu fwd1 %llu x1regs+x2fill %llu fwd2 %llu products %llu inv1 %llu out1+yrfill %llu inv2 %llu store %llu\n",
                (int)blockIdx.x, st_items, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8]);
 #endif
