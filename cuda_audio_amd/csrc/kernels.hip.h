@@ -771,12 +771,26 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
 #define IW_WAVES 16            // 15 blocks of the tile + the block before it: a multiple of the four SIMDs, two workgroups
 #define IW_NEW (IW_WAVES - 1)  // fill a CU's 32 wave slots (nine-wave workgroups put three waves on one SIMD: only two fit)
 #define IW_THREADS (64 * IW_WAVES)
+// (Q1/Q2 prefix sums: the chunk bases ride along as extra workgroups of this launch, see CorrArgs below)
+struct CorrFixArgs {
+    int T, rc, nchunks;  // nchunks = 0: nothing rides along
+    double* cring;
+    int64_t tabs0;
+    const double* ctot;
+};
+__device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], int T, double* __restrict__ cring, int rc, int64_t tabs0,
+                                              const double* __restrict__ ctot);
+
 __global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                                         int T, float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet,
-                                                        int wr, int64_t tau0, const float2* __restrict__ g_tw) {
+                                                        int wr, int64_t tau0, const float2* __restrict__ g_tw, CorrFixArgs cf, int main_grid) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ __align__(16) float2 s_mem[IW_WAVES * FFT_WAVE_LDS];  // tile [256 bins][16 blocks + 1] of float4, then 16 transforms
     static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (IW_WAVES + 1), "tile fits the transform buffers");
+    if ((int)blockIdx.x >= main_grid) {  // a workgroup that rides along: chunk base of the Q1/Q2 prefix sums
+        corr_fix_body((int)blockIdx.x - main_grid, reinterpret_cast<double(*)[4]>(s_mem), cf.T, cf.cring, cf.rc, cf.tabs0, cf.ctot);
+        return;
+    }
     float4(*s_tile)[IW_WAVES + 1] = reinterpret_cast<float4(*)[IW_WAVES + 1]>(s_mem);
     load_twiddles(s_tw, g_tw);
     const int tb0 = blockIdx.x * IW_NEW;
@@ -959,49 +973,73 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
 //                 the chunks before it.  Afterwards cring[t] = cumulative {D_L, D_R, Q_L, Q_R} up to block t.
 #define CORR_CHUNK 256
 
-__global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(const float4* __restrict__ sums, const BlockParams* __restrict__ ptab,
-                                                           int pstride, int T, VoiceSums vs, double inv_n, int compat,
-                                                           double* __restrict__ cring, int rc, int64_t tabs0,
-                                                           double* __restrict__ ctot, int need_a0, int need_a1, int need_b0) {
+// Arguments of the two prefix-sum steps.  They are tiny (one workgroup per 256 blocks) and depend only on the block sums
+// k_fwd leaves, so on the headline path they do not get launches of their own: the terms ride along as extra
+// workgroups of the k_g2_mac launch, the chunk bases as extra workgroups of the k_inv_wet launch that follows
+// (5 us each as kernels: launch and drain latency, not work).
+struct CorrArgs {
+    const float4* sums;
+    const BlockParams* ptab;
+    int pstride, T;
+    VoiceSums vs;
+    double inv_n;
+    int compat;
+    double* cring;
+    int rc;
+    int64_t tabs0;
+    double* ctot;
+    int need_a0, need_a1, need_b0;
+    int nchunks;  // 0: nothing rides along
+};
+
+// chunk cb (256 blocks) of the batch: Q1/Q2 terms, inclusive scan inside the chunk, chunk total.  Any workgroup size
+// >= CORR_CHUNK: threads beyond it only keep the barriers company.
+__device__ __forceinline__ void corr_terms_body(const int cb, double (*s_part)[4], const CorrArgs& A) {
     // blocks outside [need_a0, need_a1) and [need_b0, T) were not transformed (block-sliced rank): zero terms
     // T <= CORR_CHUNK (one workgroup): the base of the previous batch is added here and k_corr_fix is not run
-    __shared__ double s_part[CORR_CHUNK][4];
     const int tid = threadIdx.x;
-    const int t = blockIdx.x * CORR_CHUNK + tid;
+    const bool on = tid < CORR_CHUNK;
+    const int t = cb * CORR_CHUNK + tid;
     double d[4] = {0, 0, 0, 0};
-    if (t < T && compat && ((t >= need_a0 && t < need_a1) || t >= need_b0)) corr_terms(sums[t], ptab[(int64_t)t * pstride], vs, inv_n, d);
-    if (T <= CORR_CHUNK && tid == 0 && tabs0 > 0) {
-        const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
+    if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0))
+        corr_terms(A.sums[t], A.ptab[(int64_t)t * A.pstride], A.vs, A.inv_n, d);
+    if (A.T <= CORR_CHUNK && tid == 0 && A.tabs0 > 0) {
+        const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) d[c] += p[c];
     }
-    for (int c = 0; c < 4; c++) s_part[tid][c] = d[c];
+    if (on)
+        for (int c = 0; c < 4; c++) s_part[tid][c] = d[c];
     __syncthreads();
     for (int off = 1; off < CORR_CHUNK; off <<= 1) {  // inclusive Hillis-Steele scan
         double v[4] = {0, 0, 0, 0};
-        if (tid >= off)
+        if (on && tid >= off)
             for (int c = 0; c < 4; c++) v[c] = s_part[tid - off][c];
         __syncthreads();
-        for (int c = 0; c < 4; c++) s_part[tid][c] += v[c];
+        if (on)
+            for (int c = 0; c < 4; c++) s_part[tid][c] += v[c];
         __syncthreads();
     }
-    if (t < T) {
-        double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
+    if (on && t < A.T) {
+        double* o = A.cring + (size_t)((A.tabs0 + t) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) o[c] = s_part[tid][c];
     }
     if (tid == CORR_CHUNK - 1)
-        for (int c = 0; c < 4; c++) ctot[blockIdx.x * 4 + c] = s_part[tid][c];
+        for (int c = 0; c < 4; c++) A.ctot[cb * 4 + c] = s_part[tid][c];
 }
 
-__global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restrict__ cring, int rc, int64_t tabs0,
-                                                         const double* __restrict__ ctot) {
-    __shared__ double s_red[CORR_CHUNK][4];
+// chunk cb: add the totals of the chunks before it (and the previous batch's last prefix entry) to its entries
+__device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], int T, double* __restrict__ cring, int rc, int64_t tabs0,
+                                              const double* __restrict__ ctot) {
     const int tid = threadIdx.x;
-    const int t = blockIdx.x * CORR_CHUNK + tid;
+    const bool on = tid < CORR_CHUNK;
+    const int t = cb * CORR_CHUNK + tid;
     // totals of the chunks before this one: strided partial sums, then a tree in LDS (long batches have hundreds)
     double part[4] = {0, 0, 0, 0};
-    for (int k = tid; k < (int)blockIdx.x; k += CORR_CHUNK)
-        for (int c = 0; c < 4; c++) part[c] += ctot[k * 4 + c];
-    for (int c = 0; c < 4; c++) s_red[tid][c] = part[c];
+    if (on)
+        for (int k = tid; k < cb; k += CORR_CHUNK)
+            for (int c = 0; c < 4; c++) part[c] += ctot[k * 4 + c];
+    if (on)
+        for (int c = 0; c < 4; c++) s_red[tid][c] = part[c];
     __syncthreads();
     for (int off = CORR_CHUNK / 2; off > 0; off >>= 1) {
         if (tid < off)
@@ -1014,10 +1052,21 @@ __global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restri
         const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) base[c] += p[c];
     }
-    if (t < T) {
+    if (on && t < T) {
         double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
         for (int c = 0; c < 4; c++) o[c] += base[c];
     }
+}
+
+__global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(CorrArgs A) {
+    __shared__ double s_part[CORR_CHUNK][4];
+    corr_terms_body((int)blockIdx.x, s_part, A);
+}
+
+__global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restrict__ cring, int rc, int64_t tabs0,
+                                                         const double* __restrict__ ctot) {
+    __shared__ double s_red[CORR_CHUNK][4];
+    corr_fix_body((int)blockIdx.x, s_red, T, cring, rc, tabs0, ctot);
 }
 
 // ---------------------------------------------------------------------------
@@ -2835,9 +2884,14 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac_wide(const float4* __rest
 #define G2B_FILL 16  // window rows requested together (all of them: one round of memory latency)
 #endif
 __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
-                                                           int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems) {
+                                                           int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems,
+                                                           CorrArgs ca, int main_grid) {
     __shared__ float2 s[G2_LDS];
     __shared__ float2 t_lo[128], t_hi[64];
+    if ((int)blockIdx.x >= main_grid) {  // a workgroup that rides along: Q1/Q2 terms of 256 blocks (see CorrArgs)
+        corr_terms_body((int)blockIdx.x - main_grid, reinterpret_cast<double(*)[4]>(s), ca);
+        return;
+    }
     const int nch = nitems >> 8;
     g2_tables(t_lo, t_hi);
     __syncthreads();  // the first forward pass runs on registers: nothing else orders its twiddle reads after the tables
@@ -2858,7 +2912,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
     constexpr int ROWS = G2_N / G2B_THREADS;        // 16 window entries per thread and sequence
     constexpr int WS = G2B_THREADS + G2B_THREADS / 32;  // LDS distance of entries 512 apart
     constexpr int PS = 2 * G2B_THREADS + 2 * G2B_THREADS / 32;  // ... of entry pairs 2 j, 2 (j + 512)
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    for (int item = blockIdx.x; item < nitems; item += main_grid) {
         const int xq = item >> 3;
         const int bin = (xq / nch) * 8 + (item & 7), chunk = xq % nch;
         const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;

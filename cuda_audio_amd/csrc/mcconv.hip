@@ -85,6 +85,7 @@ struct BatchCtx {
     int need_a0 = 0, need_a1 = 0, need_b0 = 0;  // blocks the front half transformed: [a0, a1) and [b0, T)
     uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
     bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
+    bool corr_terms_done = false, corr_fix_done = false;  // the Q1/Q2 prefix steps rode along with the front half's launches
 };
 
 // One voice as the MAC sees it
@@ -231,6 +232,7 @@ struct mc_engine {
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
     int g2_grid = 1 << 30;   // workgroups of k_g2_mac, capped by the number of (bin, chunk) items (default: one per item); MCCONV_G2_GRID
+    bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
     bool g2_wide = false;    // MCCONV_G2_WIDE=1: the one-workgroup-per-CU form of the kernel (1024 threads, both sequences in LDS)
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
@@ -740,17 +742,27 @@ struct MacOut {
     const float4* tail_ysrc;
     int64_t tail_sk, tail_stt;
     int tail_nsum;
+    bool corr_terms_done;  // the Q1/Q2 terms rode along with the launch (k_g2_mac)
 };
 
 // inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0` -
 // or, to_wet, overlap-added straight into the wet ring (only the last block of a launch then stays in the segment ring)
-void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, bool to_wet = false) {
+// fix != null: the chunk bases of the Q1/Q2 prefix sums ride along with the first k_inv_wet launch (*fix_done says so)
+void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, bool to_wet = false, const CorrFixArgs* fix = nullptr,
+                bool* fix_done = nullptr) {
     auto inv = [&](const float4* y, int64_t sk, int64_t stt, int nsum, int64_t sc, int n, uint64_t b) {
         const int seg0 = (int)(b & (uint64_t)(e->sr - 1));
-        if (to_wet)
-            hipLaunchKernelGGL(k_inv_wet, dim3((n + IW_NEW - 1) / IW_NEW), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
-                               e->sr, seg0, e->d_wet, e->wr, (int64_t)b * MC_B, e->d_tw);
-        else
+        if (to_wet) {
+            CorrFixArgs cf;
+            std::memset(&cf, 0, sizeof(cf));
+            const int main_grid = (n + IW_NEW - 1) / IW_NEW;
+            if (fix && fix_done && !*fix_done) {
+                cf = *fix;
+                *fix_done = true;
+            }
+            hipLaunchKernelGGL(k_inv_wet, dim3(main_grid + cf.nchunks), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
+                               e->sr, seg0, e->d_wet, e->wr, (int64_t)b * MC_B, e->d_tw, cf, main_grid);
+        } else
             hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr,
                                seg0, e->d_tw);
     };
@@ -798,7 +810,10 @@ bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
 // per_slot_gains: the batch's blocks (or the window) do not share one set of gains.
-int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T, int slot0, MacOut* mo) {
+// ride != null: the Q1/Q2 terms may ride along with the launch (mo->corr_terms_done says whether they did)
+int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T, int slot0, MacOut* mo,
+                     const CorrArgs* ride = nullptr) {
+    mo->corr_terms_done = false;
     mo->resident = T >= e->stream_threshold && !e->half;
     mo->swept = 0;
     mo->sc = 1;
@@ -861,9 +876,17 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 if (e->g2_wide)  // the one-workgroup-per-CU form (MCCONV_G2_WIDE=1)
                     hipLaunchKernelGGL(k_g2_mac_wide, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl,
                                        e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
-                else
-                    hipLaunchKernelGGL(k_g2_mac, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2B_THREADS), 0, e->stream, e->d_fdl, e->ring,
-                                       slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
+                else {
+                    CorrArgs ca;
+                    std::memset(&ca, 0, sizeof(ca));
+                    if (ride && ride->nchunks > 0) {
+                        ca = *ride;
+                        mo->corr_terms_done = true;
+                    }
+                    const int main_grid = std::min(MC_NB * nch, e->g2_grid);
+                    hipLaunchKernelGGL(k_g2_mac, dim3(main_grid + ca.nchunks), dim3(G2B_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T,
+                                       chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch, ca, main_grid);
+                }
                 mo->ysrc = e->d_Yc;
                 mo->sk = e->Tcap;
                 mo->stt = 1;
@@ -1238,7 +1261,29 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
             }
             MacOut mo;
-            int rc = launch_mac_batch(e, st.act, st.nact, per_slot, n, (int)(b & (uint64_t)(e->ring - 1)), &mo);
+            // the Q1/Q2 prefix sums of the batch ride along with this launch and the inverse transforms' (fused form only;
+            // they read nothing but the block sums k_fwd left and are needed first by k_post)
+            CorrArgs ca;
+            std::memset(&ca, 0, sizeof(ca));
+            const bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && e->corr_ride;
+            if (may_ride) {
+                ca.sums = d_sums;
+                ca.ptab = d_ptab;
+                ca.pstride = pstride;
+                ca.T = T;
+                ca.vs = st.ctx.vs;
+                ca.inv_n = 1.0 / (double)e->cfg.n_ref;
+                ca.compat = (int)e->cfg.compat;
+                ca.cring = e->d_cring;
+                ca.rc = e->rc;
+                ca.tabs0 = (int64_t)st.ctx.t0;
+                ca.ctot = e->d_ctot;
+                ca.need_a0 = need_a0;
+                ca.need_a1 = need_a1;
+                ca.need_b0 = need_b0;
+                ca.nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
+            }
+            int rc = launch_mac_batch(e, st.act, st.nact, per_slot, n, (int)(b & (uint64_t)(e->ring - 1)), &mo, may_ride ? &ca : nullptr);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
@@ -1251,7 +1296,25 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 HIP_TRY(hipEventRecord(e->ev_mac[par][h], e->stream));
                 HIP_TRY(hipStreamWaitEvent(inv_stream, e->ev_mac[par][h], 0));
             }
-            launch_inv(e, mo, b, inv_stream, to_wet);
+            {
+                CorrFixArgs cf;
+                std::memset(&cf, 0, sizeof(cf));
+                bool fix_done = false;
+                if (mo.corr_terms_done) {
+                    cf.T = T;
+                    cf.rc = e->rc;
+                    cf.nchunks = ca.nchunks;
+                    cf.cring = e->d_cring;
+                    cf.tabs0 = (int64_t)st.ctx.t0;
+                    cf.ctot = e->d_ctot;
+                }
+                launch_inv(e, mo, b, inv_stream, to_wet, mo.corr_terms_done ? &cf : nullptr, &fix_done);
+                if (mo.corr_terms_done) {
+                    mc_engine::BatchCtx& stored = e->pipe[(e->pipe_head + e->pipe_count) % kPipe];
+                    stored.corr_terms_done = true;
+                    stored.corr_fix_done = fix_done;
+                }
+            }
             if (piped && h == 0 && count < e->stream_threshold) {
                 // both parts would use the streaming kernel's partial buffer: the second waits for the first's reader
                 HIP_TRY(hipEventRecord(e->ev_mac[par][0], inv_stream));
@@ -1284,10 +1347,27 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
         // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
         const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
-        hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, d_sums, d_ptab, ctx.pstride, T, ctx.vs,
-                           1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, e->d_cring, e->rc, (int64_t)ctx.t0, e->d_ctot, ctx.need_a0,
-                           ctx.need_a1, ctx.need_b0);
-        if (nchunks > 1)  // a single chunk adds its base itself
+        if (!ctx.corr_terms_done) {  // (on the headline path both steps rode along with the front half's launches)
+            CorrArgs ca;
+            std::memset(&ca, 0, sizeof(ca));
+            ca.sums = d_sums;
+            ca.ptab = d_ptab;
+            ca.pstride = ctx.pstride;
+            ca.T = T;
+            ca.vs = ctx.vs;
+            ca.inv_n = 1.0 / (double)e->cfg.n_ref;
+            ca.compat = (int)e->cfg.compat;
+            ca.cring = e->d_cring;
+            ca.rc = e->rc;
+            ca.tabs0 = (int64_t)ctx.t0;
+            ca.ctot = e->d_ctot;
+            ca.need_a0 = ctx.need_a0;
+            ca.need_a1 = ctx.need_a1;
+            ca.need_b0 = ctx.need_b0;
+            ca.nchunks = nchunks;
+            hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
+        }
+        if (nchunks > 1 && !ctx.corr_fix_done)  // a single chunk adds its base itself
             hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
                                e->d_ctot);
         const bool piped = e->pipelined && !lin_sum && !publish;
@@ -2094,6 +2174,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     // (any grid >= 1 is correct: a workgroup strides over the items; multiples of 8 keep a bin's chunks on one XCD)
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
+    if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
