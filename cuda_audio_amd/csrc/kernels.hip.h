@@ -2877,6 +2877,20 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_mac_wide(const float4* __rest
 // Bounds: as for the one-workgroup form above (items, window, spectra rows, sums); LDS: G2_P(8191) < G2_LDS.
 // ---------------------------------------------------------------------------
 #define G2B_THREADS 512
+// The 8/2 pass in a wave-local mapping: lane l of wave w works on parity l >> 5 of group 32 w + (l & 31) - the 32 groups
+// (1024 consecutive elements) that the same wave's 128/32 pass reads and writes.  The two passes therefore hand over
+// inside a wave: LDS operations of one wave execute in order, so no workgroup barrier sits between them (#if 0: the
+// barrier form, same mapping) and the waves of a workgroup drift apart instead of meeting 4 more times per item.
+// Consecutive lanes are 33 entries apart as before: conflict-free.
+#define G2B_POS1(tt) (((32 * ((tt) >> 6) + ((tt) & 31)) << 5) + (((tt) >> 5) & 1))
+#ifndef G2B_WAVE_LOCAL
+#define G2B_WAVE_LOCAL 1
+#endif
+#if G2B_WAVE_LOCAL
+#define G2B_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define G2B_WAVE_SYNC() __syncthreads()
+#endif
 #ifndef G2B_AHEAD
 #define G2B_AHEAD 1  // entry pairs by which the spectra loads run ahead of the products (4 loads of 16 bytes each)
 #endif
@@ -2952,8 +2966,8 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x1);  // quarter lengths 2048, 512
             __syncthreads();
             g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);  // 128, 32
-            __syncthreads();
-            g2_pair<false, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);  // 8, 2
+            G2B_WAVE_SYNC();  // a wave's 1024 elements of this pass are the 32 groups its last pass works on
+            g2_pair<false, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);  // 8, 2
             __syncthreads();
             G2_STAMP(1);
             // ---- own entries of X1 (pairs 2 j, 2 j + 1, j = tt + 512 r; the radix-2 stage on the way) to registers
@@ -2973,8 +2987,8 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x2);
             __syncthreads();
             g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
-            __syncthreads();
-            g2_pair<false, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
+            G2B_WAVE_SYNC();
+            g2_pair<false, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
             __syncthreads();
             G2_STAMP(3);
             // ---- products: Y_c = sum_voices g (X1 H1c + X2 H2c) on the thread's own entries; Y_L replaces X2 in LDS,
@@ -3036,8 +3050,8 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             G2_STAMP(4);
             // ---- inverse of Y_L; its last pass leaves element tt + 512 m = output block tt + 512 m - (taps - 1) in registers
             v2f yl[ROWS];
-            g2_pair<true, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
-            __syncthreads();
+            g2_pair<true, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
+            G2B_WAVE_SYNC();
             g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
             __syncthreads();
             g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yl);
@@ -3056,8 +3070,8 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
             G2_STAMP(6);
             {
                 v2f yr[ROWS];
-                g2_pair<true, 1>(s, t_lo, t_hi, ((tt & 255) << 5) + (tt >> 8), tt >> 8);
-                __syncthreads();
+                g2_pair<true, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
+                G2B_WAVE_SYNC();
                 g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
                 __syncthreads();
                 g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yr);
