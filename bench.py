@@ -442,7 +442,7 @@ def main():
         if not a.no_host_io and a.mode == "resident" and npairs == 1:
             e = eng[0]
             e.set_stream(None)
-            nst = 6
+            nst = 10
             hin, hout = e.pinned_array((2, nst * T * BLOCK)), e.pinned_array((2, nst * T * BLOCK))
             for k in range(nst):
                 o = (k % n_distinct) * T * BLOCK

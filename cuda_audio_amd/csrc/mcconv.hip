@@ -165,10 +165,12 @@ struct mc_engine {
     int Thost = 0;                                          // blocks per chunk of a host-buffer batch staged through h_io
     // host-buffer batches whose buffers are pinned (mc_host_alloc, hipHostMalloc, hipHostRegister): chunks of Tdev blocks,
     // H2D / compute / D2H on three streams, two chunks in flight; device staging allocated on first use
-    float* d_pio[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    // (three staging sets: with two, copy-in waiting for the kernels of chunk k - 2 and the kernels waiting for the copy-out of
+    // chunk k - 2 lock the three streams into taking turns - 2.9 instead of 1.5 ms per 32320-block chunk, scripts/pcie_pipeline_probe.py)
+    float* d_pio[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     int Tdev = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr}, ev_comp[3] = {nullptr, nullptr, nullptr}, ev_d2h[3] = {nullptr, nullptr, nullptr};
     float* h_io = nullptr;                                  // pinned mirror of d_io, 4 * Thost * 256
     float* hd_io = nullptr;                                 // device-side address of h_io (mapped, zero-copy)
     unsigned* h_flag = nullptr;                             // completion word of the single-period path (mapped)
@@ -1798,18 +1800,19 @@ int process_host_staged(mc_engine* e, const float* in1, const float* in2, float*
 
 // Host-buffer batch with pinned caller memory: the DMA engines read and write the caller's buffers directly.  Chunks
 // of Tdev blocks; chunk k's copy-in (H2D stream), chunk k - 1's kernels (engine stream) and chunk k - 2's copy-out
-// (D2H stream) run together.  Returns when the last output byte is in outL / outR.
+// (D2H stream) run together, over three staging sets.  Returns when the last output byte is in outL / outR.
 int process_host_pinned(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int T) {
     if (!e->Tdev) {
-        // one chunk of the second-level transform where it applies: short enough that copy-in, kernels and copy-out of
-        // neighbouring chunks overlap well (the copies, not the kernels, set the pace)
-        int tdev = (int)std::min<uint64_t>(mc_preferred_batch(e, std::min(e->Tmax, 8192)), (uint64_t)e->Tmax);
+        // whole chunks of the second-level transform where it applies, and LONG ones: the copies set the pace, and the
+        // link carries 45-48 GB/s each way at once in copies of >= 33 MB but only 26 GB/s in 6.6 MB ones
+        // (scripts/pcie_probe.py; 53-57 GB/s one way at a time)
+        int tdev = (int)std::min<uint64_t>(mc_preferred_batch(e, std::min(e->Tmax, 32768)), (uint64_t)e->Tmax);
         tdev = std::max(tdev / e->pm * e->pm, e->pm);
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < 3; b++)
             for (int i = 0; i < 4; i++) HIP_TRY(hipMalloc(&e->d_pio[b][i], sizeof(float) * (size_t)tdev * MC_B));
         HIP_TRY(hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < 3; b++) {
             HIP_TRY(hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&e->ev_comp[b], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&e->ev_d2h[b], hipEventDisableTiming));
@@ -1818,16 +1821,16 @@ int process_host_pinned(mc_engine* e, const float* in1, const float* in2, float*
     }
     int k = 0;
     for (int o = 0; o < T; o += e->Tdev, k++) {
-        const int n = std::min(e->Tdev, T - o), b = k & 1;
+        const int n = std::min(e->Tdev, T - o), b = k % 3;
         const size_t bytes = (size_t)n * MC_B * sizeof(float), off = (size_t)o * MC_B;
         float* const* d = e->d_pio[b];
-        // the staging pair is free once chunk k - 2 has been computed (inputs) and copied out (outputs)
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->h2d_stream, e->ev_comp[b], 0));
+        // the staging set is free once chunk k - 3 has been computed (inputs) and copied out (outputs)
+        if (k >= 3) HIP_TRY(hipStreamWaitEvent(e->h2d_stream, e->ev_comp[b], 0));
         HIP_TRY(hipMemcpyAsync(d[0], in1 + off, bytes, hipMemcpyHostToDevice, e->h2d_stream));
         HIP_TRY(hipMemcpyAsync(d[1], in2 + off, bytes, hipMemcpyHostToDevice, e->h2d_stream));
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_d2h[b], 0));
+        if (k >= 3) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_d2h[b], 0));
         int rc = run_front(e, d[0], d[1], n, nullptr, 0, n);
         if (rc) return rc;
         rc = run_back(e, d[0], d[1], nullptr, d[2], d[3], n);
@@ -2251,7 +2254,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_ptab);
     (void)hipFree(e->d_tw);
     for (int i = 0; i < 4; i++) (void)hipFree(e->d_io[i]);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < 3; b++) {
         for (int i = 0; i < 4; i++) (void)hipFree(e->d_pio[b][i]);
         if (e->ev_h2d[b]) (void)hipEventDestroy(e->ev_h2d[b]);
         if (e->ev_comp[b]) (void)hipEventDestroy(e->ev_comp[b]);
