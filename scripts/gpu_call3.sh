@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 bash scripts/profile_r2.sh headline || exit 1
 
-MCCONV_G2_WIDE=1 bash scripts/profile_r2.sh wide || true
+MCCONV_G2_WIDE=1 MCCONV_CORR_RIDE=0 bash scripts/profile_r2.sh wide || true
 bash scripts/profile_jack.sh || true
 echo "== bench lines"
 run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/bench_$n.json 2> gpurun_out/bench_$n.err; echo "$n rc=$?"; }
