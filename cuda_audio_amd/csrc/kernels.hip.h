@@ -2924,7 +2924,6 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
 #define G2_STAMP(k) do { } while (0)
 #endif
     constexpr int ROWS = G2_N / G2B_THREADS;        // 16 window entries per thread and sequence
-    constexpr int WS = G2B_THREADS + G2B_THREADS / 32;  // LDS distance of entries 512 apart
     constexpr int PS = 2 * G2B_THREADS + 2 * G2B_THREADS / 32;  // ... of entry pairs 2 j, 2 (j + 512)
     for (int item = blockIdx.x; item < nitems; item += main_grid) {
         const int xq = item >> 3;

@@ -1106,7 +1106,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
     while (F > 0) {
         int Tc = std::min(F, e->Tcap);
         if (!(Tc >= e->stream_threshold && !e->half)) Tc = std::min(Tc, e->Tstream);
-        const int slot0 = (int)(tv & (uint64_t)(e->ring - 1)), seg0 = (int)(tv & (uint64_t)(e->sr - 1));
+        const int slot0 = (int)(tv & (uint64_t)(e->ring - 1));
         // silent blocks into the delay line (n_frames = 0: the inputs are never read)
         hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
