@@ -212,6 +212,9 @@ def labelled_profile(name, key=None):
                                              stderr=subprocess.DEVNULL).decode().strip() or None
         except Exception:
             commit = None
+        if commit is None:  # (no git on the GPU box: the summariser stamped the commit the profile was taken at)
+            probe = d if isinstance(d, dict) else {}
+            commit = probe.get("profiled_at_commit") or next((v.get("profiled_at_commit") for v in probe.values() if isinstance(v, dict)), None)
         return {"data": d, "from": "profiles/" + name, "commit": commit,
                 "note": "copied from a committed rocprofv3 profile of the same command, NOT measured in this run"}
     except Exception:

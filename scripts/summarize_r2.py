@@ -11,6 +11,7 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +33,13 @@ def counters(src, name):
             seen.add((k, did))
             dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return out, dur
+
+
+def head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
 
 def mean(v):
@@ -109,7 +117,8 @@ def main(tag, dominant, blocks=None):
             der["l2_hit_rate"] = round(g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1), 4)
         der = {a: b for a, b in der.items() if b is not None}
         lines += ["", "Derived:", ""] + [f"- {a}: {b}" for a, b in der.items()]
-        g2 = {"kernel": k, "avg_us": t_us, "counters": c, "derived": der, "command": cmd,
+        der["profiled_at_commit"] = head()
+        g2 = {"kernel": k, "avg_us": t_us, "counters": c, "derived": der, "command": cmd, "profiled_at_commit": head(),
               "durations_us_per_pass": durs.get(k)}
         if blocks:
             g2["blocks_per_launch"] = int(blocks)
@@ -127,6 +136,7 @@ def main(tag, dominant, blocks=None):
         if blocks:
             v["blocks_per_launch"] = int(blocks)
         v["command"] = cmd
+        v["profiled_at_commit"] = head()
         data.setdefault(tag, {})[k] = v
     json.dump(data, open(tj, "w"), indent=1)
     print("\n".join(lines[:60]))
