@@ -1489,7 +1489,8 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
     p0, p1 = dict(BASE, select=0), dict(BASE, select=1)
 
     def run(direct, T=None):
-        monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")
+        monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")  # (the suite is also run with the measurement switches set)
+        monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
         c = _conv(fftSize=n_ref, max_batch=32768)
         for i, ir in enumerate(irs):
@@ -1555,6 +1556,8 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     x = torch.from_numpy(make_input((T0 + T) * 256)).to(dev)
 
     def run(grid, wide=False):
+        monkeypatch.setenv("MCCONV_FFT2", "1")  # (the suite is also run with the measurement switches set)
+        monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
         monkeypatch.setenv("MCCONV_G2_WIDE", "1" if wide else "0")
         if grid is None:
             monkeypatch.delenv("MCCONV_G2_GRID", raising=False)
@@ -1632,7 +1635,7 @@ def test_pinned_host_batches_overlap_copies_and_match(oracle_mod, gpu_lib):
         assert err <= RMS_TOL, f"blocks from {b0}: rms {err:.3e}"
 
 
-def test_config4_partition_shards_at_full_size(oracle_mod, gpu_lib):
+def test_config4_partition_shards_at_full_size(oracle_mod, gpu_lib, monkeypatch):
     """BASELINE config 4 at its stated shape, one stereo pair of the four (main.cu:31-39: one Convolution per pair):
     10 s IRs (441 000 taps, 1723 partitions) sharded over 8 engines - virtual ranks on one GPU, the sum of the partial
     wet blocks stands in for the RCCL reduce - in batches of the shard's preferred length.  A shard is a 224-tap
@@ -1643,6 +1646,8 @@ def test_config4_partition_shards_at_full_size(oracle_mod, gpu_lib):
     from cuda_audio_amd.sharded import shard_bounds
     from cuda_audio_amd.synth import make_input, make_ir
 
+    monkeypatch.setenv("MCCONV_FFT2", "1")  # (the suite is also run with the measurement switches set)
+    monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
     dev = torch.device("cuda:0")
     n_ref, G = 524288, 8
     irs = [make_ir(441000, seed=5678), make_ir(441000, seed=5680)]
