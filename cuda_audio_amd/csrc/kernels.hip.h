@@ -771,26 +771,66 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
 #define IW_WAVES 16            // 15 blocks of the tile + the block before it: a multiple of the four SIMDs, two workgroups
 #define IW_NEW (IW_WAVES - 1)  // fill a CU's 32 wave slots (nine-wave workgroups put three waves on one SIMD: only two fit)
 #define IW_THREADS (64 * IW_WAVES)
-// (Q1/Q2 prefix sums: the chunk bases ride along as extra workgroups of this launch, see CorrArgs below)
-struct CorrFixArgs {
-    int T, rc, nchunks;  // nchunks = 0: nothing rides along
-    double* cring;
-    int64_t tabs0;
-    const double* ctot;
+// OUT: the launch also finishes the output (what k_post does for the general case): Q1/Q2 window sums, clamp, dry mix,
+// shifted by the predelay - for batches with no Q8 pass, no retired predelay epoch ringing out and final prefix sums
+// (cring) at launch.  The wet signal then never makes the 8 bytes per frame round trip through memory; only the blocks
+// later calls can reach (the last 8192 + frames) and the first block(s), which k_post finishes when the predelay
+// reaches back into the previous batch, are still written to the wet ring.
+struct OutArgs {
+    const float *in1, *in2;  // the batch's input [T * 256] each
+    float *outL, *outR;      // the batch's output
+    const BlockParams* ptab;
+    int pstride;
+    const double* cring;
+    int rc;
+    int64_t tabs0;  // first block of the batch (absolute)
+    int64_t predelay, n_ref, b0;  // b0: first block of the live predelay epoch
+    int compat, pm;
+    int T;                   // blocks in the batch
+    int blk0;                // block of the batch this launch starts at
+    int out_from;            // output blocks < out_from are left to k_post (they need wet samples of earlier calls)
+    int wet_head, wet_from;  // blocks of the batch < wet_head or >= wet_from also go to the wet ring
 };
-__device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], int T, double* __restrict__ cring, int rc, int64_t tabs0,
-                                              const double* __restrict__ ctot);
 
-__global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
+// Q1/Q2 window sums {D_L, D_R, Q_L, Q_R} of the wet frame u, which sounds at tau = u + predelay (the arithmetic of k_post):
+// calls q of the live epoch with predelay <= tau - q * period < n_ref; the prefix sums are per block
+__device__ __forceinline__ void out_window(const OutArgs& A, const int64_t u, double (&win)[4]) {
+    win[0] = win[1] = win[2] = win[3] = 0.0;
+    if (!A.compat) return;
+    // the last block of the call (pm blocks, a power of two) that block b belongs to: b | (pm - 1)
+    const int64_t thi = (u >> 8) | (A.pm - 1);
+    const int64_t v = u + A.predelay - A.n_ref;
+    int64_t tlo = v >= 0 ? ((v >> 8) | (A.pm - 1)) : -1;
+    if (tlo < A.b0 - 1) tlo = A.b0 - 1;
+    if (thi <= tlo) return;
+    const double* a = A.cring + (size_t)(thi & (A.rc - 1)) * 4;
+    win[0] = a[0], win[1] = a[1], win[2] = a[2], win[3] = a[3];
+    if (tlo >= 0) {
+        const double* b = A.cring + (size_t)(tlo & (A.rc - 1)) * 4;
+        win[0] -= b[0];
+        win[1] -= b[1];
+        win[2] -= b[2];
+        win[3] -= b[3];
+    }
+}
+
+__device__ __forceinline__ void out_frame(const bool odd, const float wl, const float wr, const float x1, const float x2,
+                                          const BlockParams& bp, const double (&win)[4], float& ol, float& orr) {
+    const double sg = odd ? -1.0 : 1.0;
+    const double cl = win[0] + sg * win[2], cr = win[1] + sg * win[3];
+    const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
+    const float vr = fminf(fmaxf((float)((double)wr + cr), -1.f), 1.f);
+    ol = vl + x1 * bp.d[0] + x2 * bp.d[1];
+    orr = vr + x1 * bp.d[2] + x2 * bp.d[3];
+}
+
+template <bool OUT>
+__global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_inv_wet(const float4* __restrict__ Ysrc, int64_t sk, int64_t st, int nsum, int64_t sc,
                                                         int T, float* __restrict__ seg, int sr, int seg0, float* __restrict__ wet,
-                                                        int wr, int64_t tau0, const float2* __restrict__ g_tw, CorrFixArgs cf, int main_grid) {
+                                                        int wr, int64_t tau0, const float2* __restrict__ g_tw, OutArgs oa) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ __align__(16) float2 s_mem[IW_WAVES * FFT_WAVE_LDS];  // tile [256 bins][16 blocks + 1] of float4, then 16 transforms
     static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (IW_WAVES + 1), "tile fits the transform buffers");
-    if ((int)blockIdx.x >= main_grid) {  // a workgroup that rides along: chunk base of the Q1/Q2 prefix sums
-        corr_fix_body((int)blockIdx.x - main_grid, reinterpret_cast<double(*)[4]>(s_mem), cf.T, cf.cring, cf.rc, cf.tabs0, cf.ctot);
-        return;
-    }
     float4(*s_tile)[IW_WAVES + 1] = reinterpret_cast<float4(*)[IW_WAVES + 1]>(s_mem);
     load_twiddles(s_tw, g_tw);
     const int tb0 = blockIdx.x * IW_NEW;
@@ -820,6 +860,7 @@ __global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = tb0 - 1 + wave;
+    const int m0 = 4 * lane;
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -857,15 +898,58 @@ __global__ __launch_bounds__(IW_THREADS) void k_inv_wet(const float4* __restrict
     }
     __syncthreads();
     if (wave > 0 && t < T) {
+        // OUT: the lane's four wet frames [i0, i0 + 4) of the batch sound at output frames [o0, o0 + 4)
+        const int64_t i0 = OUT ? ((int64_t)(oa.blk0 + t) * MC_B + m0) : 0;
+        const int64_t o0 = i0 + (OUT ? oa.predelay : 0);
+        const bool emits = OUT && o0 + 3 >= (int64_t)oa.out_from * MC_B && o0 < (int64_t)oa.T * MC_B;
+        const bool whole = emits && ((o0 | oa.n_ref) & 3) == 0 && o0 >= (int64_t)oa.out_from * MC_B;  // one aligned quad (then o0 + 3 is inside too)
+        float4 x1q = make_float4(0.f, 0.f, 0.f, 0.f), x2q = x1q;
+        if (whole) {
+            x1q = *reinterpret_cast<const float4*>(oa.in1 + o0);
+            x2q = *reinterpret_cast<const float4*>(oa.in2 + o0);
+        }
         const float scl = 1.0f / FFT_N;
         const float2* prev = lds - FFT_WAVE_LDS + MC_B;
-        const int m0 = 4 * lane;
-        const float2 o0 = lds[m0], o1 = lds[m0 + 1], o2 = lds[m0 + 2], o3 = lds[m0 + 3];
+        const float2 o0_ = lds[m0], o1 = lds[m0 + 1], o2 = lds[m0 + 2], o3 = lds[m0 + 3];
         const float2 p0 = prev[m0], p1 = prev[m0 + 1], p2 = prev[m0 + 2], p3 = prev[m0 + 3];
         // (a + b) / 512 == a / 512 + b / 512 exactly: the same bits as overlap-adding scaled segments
-        const size_t at = (size_t)((tau0 + (int64_t)t * MC_B + m0) & (wr - 1));
-        *reinterpret_cast<float4*>(wet + at) = make_float4((o0.x + p0.x) * scl, (o1.x + p1.x) * scl, (o2.x + p2.x) * scl, (o3.x + p3.x) * scl);
-        *reinterpret_cast<float4*>(wet + wr + at) = make_float4((o0.y + p0.y) * scl, (o1.y + p1.y) * scl, (o2.y + p2.y) * scl, (o3.y + p3.y) * scl);
+        const float4 wl4 = make_float4((o0_.x + p0.x) * scl, (o1.x + p1.x) * scl, (o2.x + p2.x) * scl, (o3.x + p3.x) * scl);
+        const float4 wr4 = make_float4((o0_.y + p0.y) * scl, (o1.y + p1.y) * scl, (o2.y + p2.y) * scl, (o3.y + p3.y) * scl);
+        if (!OUT || oa.blk0 + t < oa.wet_head || oa.blk0 + t >= oa.wet_from) {
+            const size_t at = (size_t)((tau0 + (int64_t)t * MC_B + m0) & (wr - 1));
+            *reinterpret_cast<float4*>(wet + at) = wl4;
+            *reinterpret_cast<float4*>(wet + wr + at) = wr4;
+        }
+        if (emits) {
+            const int64_t u0 = oa.tabs0 * MC_B + i0;
+            double win[4];
+            if (whole) {
+                // four frames of one block, and (predelay, n_ref multiples of four) of one window
+                out_window(oa, u0, win);
+                const BlockParams& bp = oa.ptab[(o0 >> 8) * oa.pstride];
+                float4 fl, fr;
+                out_frame(false, wl4.x, wr4.x, x1q.x, x2q.x, bp, win, fl.x, fr.x);
+                out_frame(true, wl4.y, wr4.y, x1q.y, x2q.y, bp, win, fl.y, fr.y);
+                out_frame(false, wl4.z, wr4.z, x1q.z, x2q.z, bp, win, fl.z, fr.z);
+                out_frame(true, wl4.w, wr4.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
+                *reinterpret_cast<float4*>(oa.outL + o0) = fl;
+                *reinterpret_cast<float4*>(oa.outR + o0) = fr;
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {  // a predelay that is no multiple of four frames: frame by frame (rolled: registers)
+                    const int64_t o = o0 + k;
+                    if (o < (int64_t)oa.out_from * MC_B || o >= (int64_t)oa.T * MC_B) continue;
+                    const BlockParams& bp = oa.ptab[(o >> 8) * oa.pstride];
+                    const float a = k == 0 ? wl4.x : (k == 1 ? wl4.y : (k == 2 ? wl4.z : wl4.w));
+                    const float b = k == 0 ? wr4.x : (k == 1 ? wr4.y : (k == 2 ? wr4.z : wr4.w));
+                    float fl, fr;
+                    out_window(oa, u0 + k, win);
+                    out_frame((k & 1) != 0, a, b, oa.in1[o], oa.in2[o], bp, win, fl, fr);
+                    oa.outL[o] = fl;
+                    oa.outR[o] = fr;
+                }
+            }
+        }
         if (t == T - 1) {  // the launch's last block stays in the segment ring in full
             float* dst = seg + (size_t)((seg0 + t) & (sr - 1)) * 2 * FFT_N;
 #pragma unroll
@@ -990,20 +1074,36 @@ struct CorrArgs {
     double* ctot;
     int need_a0, need_a1, need_b0;
     int nchunks;  // 0: nothing rides along
+    // chain != 0 (workgroups riding along with another kernel's launch): one pass - a workgroup takes a ticket (its chunk),
+    // scans its chunk, publishes the chunk total under flags[chunk] = seq and adds the totals of the chunks before it
+    // itself, so the ring is final when the launch ends and k_corr_fix is not needed.  A workgroup waits only for
+    // lower tickets, which were taken by workgroups already running: the chain always advances.
+    int chain;
+    unsigned* ticket;      // counter the tickets come from (never reset: ticket = old value - ticket_base)
+    unsigned ticket_base;  // tickets handed out by earlier launches
+    unsigned* flags;       // [nchunks] sequence number of the launch whose total ctot[chunk] holds
+    unsigned seq;
 };
 
 // chunk cb (256 blocks) of the batch: Q1/Q2 terms, inclusive scan inside the chunk, chunk total.  Any workgroup size
 // >= CORR_CHUNK: threads beyond it only keep the barriers company.
-__device__ __forceinline__ void corr_terms_body(const int cb, double (*s_part)[4], const CorrArgs& A) {
+__device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], const CorrArgs& A) {
     // blocks outside [need_a0, need_a1) and [need_b0, T) were not transformed (block-sliced rank): zero terms
     // T <= CORR_CHUNK (one workgroup): the base of the previous batch is added here and k_corr_fix is not run
     const int tid = threadIdx.x;
     const bool on = tid < CORR_CHUNK;
+    if (A.chain) {  // the chunk is the ticket: tickets are taken in the order the workgroups start
+        __shared__ unsigned s_ticket;
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.ticket_base;
+        __syncthreads();
+        cb = (int)s_ticket;
+        if (cb < 0 || cb >= A.nchunks) return;  // (cannot happen: one ticket per riding workgroup)
+    }
     const int t = cb * CORR_CHUNK + tid;
     double d[4] = {0, 0, 0, 0};
     if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0))
         corr_terms(A.sums[t], A.ptab[(int64_t)t * A.pstride], A.vs, A.inv_n, d);
-    if (A.T <= CORR_CHUNK && tid == 0 && A.tabs0 > 0) {
+    if (!A.chain && A.T <= CORR_CHUNK && tid == 0 && A.tabs0 > 0) {
         const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) d[c] += p[c];
     }
@@ -1019,12 +1119,56 @@ __device__ __forceinline__ void corr_terms_body(const int cb, double (*s_part)[4
             for (int c = 0; c < 4; c++) s_part[tid][c] += v[c];
         __syncthreads();
     }
-    if (on && t < A.T) {
-        double* o = A.cring + (size_t)((A.tabs0 + t) & (A.rc - 1)) * 4;
-        for (int c = 0; c < 4; c++) o[c] = s_part[tid][c];
+    if (!A.chain) {
+        if (on && t < A.T) {
+            double* o = A.cring + (size_t)((A.tabs0 + t) & (A.rc - 1)) * 4;
+            for (int c = 0; c < 4; c++) o[c] = s_part[tid][c];
+        }
+        if (tid == CORR_CHUNK - 1)
+            for (int c = 0; c < 4; c++) A.ctot[cb * 4 + c] = s_part[tid][c];
+        return;
     }
-    if (tid == CORR_CHUNK - 1)
-        for (int c = 0; c < 4; c++) A.ctot[cb * 4 + c] = s_part[tid][c];
+    double own[4] = {0, 0, 0, 0};
+    if (on)
+        for (int c = 0; c < 4; c++) own[c] = s_part[tid][c];
+    if (tid == CORR_CHUNK - 1) {  // publish the chunk total
+        for (int c = 0; c < 4; c++) __hip_atomic_store(A.ctot + cb * 4 + c, own[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.flags + cb, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // everyone has its own entry in registers: the scan buffer becomes the reduction buffer
+    double part[4] = {0, 0, 0, 0};
+    bool lost = false;
+    if (on)
+        for (int k = tid; k < cb; k += CORR_CHUNK) {
+            int spins = 0;  // bounded: a total that never arrives poisons the sums (NaN) instead of hanging the GPU
+            while (__hip_atomic_load(A.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != A.seq) {
+                if (++spins > (1 << 22)) {
+                    lost = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            for (int c = 0; c < 4; c++) part[c] += __hip_atomic_load(A.ctot + k * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    if (lost) part[0] = part[1] = part[2] = part[3] = __builtin_nan("");
+    if (on)
+        for (int c = 0; c < 4; c++) s_part[tid][c] = part[c];
+    __syncthreads();
+    for (int off = CORR_CHUNK / 2; off > 0; off >>= 1) {
+        if (tid < off)
+            for (int c = 0; c < 4; c++) s_part[tid][c] += s_part[tid + off][c];
+        __syncthreads();
+    }
+    if (on && t < A.T) {
+        double base[4];
+        for (int c = 0; c < 4; c++) base[c] = s_part[0][c];
+        if (A.tabs0 > 0) {  // the previous batch's last entry (final since an earlier launch)
+            const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
+            for (int c = 0; c < 4; c++) base[c] += p[c];
+        }
+        double* o = A.cring + (size_t)((A.tabs0 + t) & (A.rc - 1)) * 4;
+        for (int c = 0; c < 4; c++) o[c] = own[c] + base[c];
+    }
 }
 
 // chunk cb: add the totals of the chunks before it (and the previous batch's last prefix entry) to its entries

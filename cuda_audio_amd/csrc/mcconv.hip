@@ -85,7 +85,8 @@ struct BatchCtx {
     int need_a0 = 0, need_a1 = 0, need_b0 = 0;  // blocks the front half transformed: [a0, a1) and [b0, T)
     uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
     bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
-    bool corr_terms_done = false, corr_fix_done = false;  // the Q1/Q2 prefix steps rode along with the front half's launches
+    bool corr_done = false;    // the Q1/Q2 prefix sums of the batch are final (they rode along with the front half's launches)
+    int out_from = -1;         // >= 0: the front half finished the output of blocks >= out_from itself (k_inv_wet<true>)
 };
 
 // One voice as the MAC sees it
@@ -235,6 +236,10 @@ struct mc_engine {
     bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
     int g2_grid = 1 << 30;   // workgroups of k_g2_mac, capped by the number of (bin, chunk) items (default: one per item); MCCONV_G2_GRID
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
+    bool fuse_out = true;    // MCCONV_FUSE_OUT=0: the output always through k_post (measurement)
+    unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
+    unsigned* d_cflag = nullptr;    // [ceil(Tmax/256)] launch sequence number per published chunk total
+    unsigned cticket_base = 0, cflag_seq = 0;
     bool g2_wide = false;    // MCCONV_G2_WIDE=1: the one-workgroup-per-CU form of the kernel (1024 threads, both sequences in LDS)
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
@@ -744,26 +749,27 @@ struct MacOut {
     const float4* tail_ysrc;
     int64_t tail_sk, tail_stt;
     int tail_nsum;
-    bool corr_terms_done;  // the Q1/Q2 terms rode along with the launch (k_g2_mac)
+    bool corr_done;  // the Q1/Q2 prefix sums rode along with the launch (k_g2_mac) and are final when it ends
 };
 
 // inverse transforms of the blocks whose partition sums `mo` describes, into the segment ring from block `b0` -
 // or, to_wet, overlap-added straight into the wet ring (only the last block of a launch then stays in the segment ring)
-// fix != null: the chunk bases of the Q1/Q2 prefix sums ride along with the first k_inv_wet launch (*fix_done says so)
-void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, bool to_wet = false, const CorrFixArgs* fix = nullptr,
-                bool* fix_done = nullptr) {
+// out != null: the launches also finish the output of their blocks (k_inv_wet<true>, see OutArgs)
+void launch_inv(mc_engine* e, const MacOut& mo, uint64_t b0, hipStream_t st, bool to_wet = false, const OutArgs* out = nullptr) {
     auto inv = [&](const float4* y, int64_t sk, int64_t stt, int nsum, int64_t sc, int n, uint64_t b) {
         const int seg0 = (int)(b & (uint64_t)(e->sr - 1));
         if (to_wet) {
-            CorrFixArgs cf;
-            std::memset(&cf, 0, sizeof(cf));
-            const int main_grid = (n + IW_NEW - 1) / IW_NEW;
-            if (fix && fix_done && !*fix_done) {
-                cf = *fix;
-                *fix_done = true;
-            }
-            hipLaunchKernelGGL(k_inv_wet, dim3(main_grid + cf.nchunks), dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg,
-                               e->sr, seg0, e->d_wet, e->wr, (int64_t)b * MC_B, e->d_tw, cf, main_grid);
+            OutArgs oa;
+            std::memset(&oa, 0, sizeof(oa));
+            const dim3 grid((n + IW_NEW - 1) / IW_NEW);
+            if (out) {
+                oa = *out;
+                oa.blk0 = (int)((int64_t)b - out->tabs0);
+                hipLaunchKernelGGL(k_inv_wet<true>, grid, dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr, seg0, e->d_wet,
+                                   e->wr, (int64_t)b * MC_B, e->d_tw, oa);
+            } else
+                hipLaunchKernelGGL(k_inv_wet<false>, grid, dim3(IW_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr, seg0, e->d_wet,
+                                   e->wr, (int64_t)b * MC_B, e->d_tw, oa);
         } else
             hipLaunchKernelGGL(k_inv, dim3((n + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, st, y, sk, stt, nsum, sc, n, e->d_seg, e->sr,
                                seg0, e->d_tw);
@@ -812,10 +818,10 @@ bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
 // per_slot_gains: the batch's blocks (or the window) do not share one set of gains.
-// ride != null: the Q1/Q2 terms may ride along with the launch (mo->corr_terms_done says whether they did)
+// ride != null: the Q1/Q2 prefix sums may ride along with the launch (mo->corr_done says whether they did)
 int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T, int slot0, MacOut* mo,
                      const CorrArgs* ride = nullptr) {
-    mo->corr_terms_done = false;
+    mo->corr_done = false;
     mo->resident = T >= e->stream_threshold && !e->half;
     mo->swept = 0;
     mo->sc = 1;
@@ -883,7 +889,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                     std::memset(&ca, 0, sizeof(ca));
                     if (ride && ride->nchunks > 0) {
                         ca = *ride;
-                        mo->corr_terms_done = true;
+                        mo->corr_done = true;
                     }
                     const int main_grid = std::min(MC_NB * nch, e->g2_grid);
                     hipLaunchKernelGGL(k_g2_mac, dim3(main_grid + ca.nchunks), dim3(G2B_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T,
@@ -1145,7 +1151,10 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
 // everything that later calls depend on (delay line, gains, Q1/Q2 sums, histories) is still produced for all T
 // blocks, the partition sums and inverse transforms only for the slice and the few blocks before it that the
 // overlap-add and the predelay reach back to.
-int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin, int first, int count) {
+// d_outL / d_outR != null: the caller finishes the batch right away (run_back follows with the same buffers), so the
+// inverse-transform launches may write the output themselves
+int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float* lin, int first, int count,
+              float* d_outL = nullptr, float* d_outR = nullptr) {
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks %d outside [1, %d]", T, e->Tmax);
     if (e->pipe_count >= kPipe) return fail(MC_ERR_STATE, "%d batches already await mc_finish_batch_device", kPipe);
     if (T % e->pm) return fail(MC_ERR_ARG, "nblocks %d is not a multiple of the period (%d blocks)", T, e->pm);
@@ -1268,7 +1277,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
             CorrArgs ca;
             std::memset(&ca, 0, sizeof(ca));
             const bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && e->corr_ride;
-            if (may_ride) {
+            auto corr_args = [&]() {
                 ca.sums = d_sums;
                 ca.ptab = d_ptab;
                 ca.pstride = pstride;
@@ -1284,9 +1293,21 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 ca.need_a1 = need_a1;
                 ca.need_b0 = need_b0;
                 ca.nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
+            };
+            if (may_ride) {
+                corr_args();
+                ca.chain = 1;
+                ca.ticket = e->d_cticket;
+                ca.ticket_base = e->cticket_base;
+                ca.flags = e->d_cflag;
+                ca.seq = e->cflag_seq + 1;
             }
             int rc = launch_mac_batch(e, st.act, st.nact, per_slot, n, (int)(b & (uint64_t)(e->ring - 1)), &mo, may_ride ? &ca : nullptr);
             if (rc) return rc;
+            if (mo.corr_done) {  // the riding workgroups took their tickets
+                e->cticket_base += (unsigned)ca.nchunks;
+                e->cflag_seq++;
+            }
             if (timed) {
                 HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
                 e->kev_n++;
@@ -1299,23 +1320,46 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 HIP_TRY(hipStreamWaitEvent(inv_stream, e->ev_mac[par][h], 0));
             }
             {
-                CorrFixArgs cf;
-                std::memset(&cf, 0, sizeof(cf));
-                bool fix_done = false;
-                if (mo.corr_terms_done) {
-                    cf.T = T;
-                    cf.rc = e->rc;
-                    cf.nchunks = ca.nchunks;
-                    cf.cring = e->d_cring;
-                    cf.tabs0 = (int64_t)st.ctx.t0;
-                    cf.ctot = e->d_ctot;
+                mc_engine::BatchCtx& stored = e->pipe[(e->pipe_head + e->pipe_count) % kPipe];
+                // The inverse transforms finish the output themselves when nothing but this batch's own wet signal and
+                // final prefix sums go into it: a whole batch on one engine, no Q8 pass, no retired epoch ringing out.
+                OutArgs oa;
+                std::memset(&oa, 0, sizeof(oa));
+                bool fuse = h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !slice && !piped && off == 0 && n == T &&
+                            e->res_end <= e->t_front * MC_B && !make_taildrop(e, st.ctx.vir, st.ctx.predelay).on;
+                if (fuse) {
+                    if (!mo.corr_done) {  // the prefix sums as launches of their own, ahead of their reader
+                        corr_args();
+                        ca.chain = 0;
+                        hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, ca);
+                        if (ca.nchunks > 1)
+                            hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, T, e->d_cring, e->rc,
+                                               (int64_t)st.ctx.t0, e->d_ctot);
+                        mo.corr_done = true;
+                    }
+                    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
+                    oa.in1 = d_in1;
+                    oa.in2 = d_in2;
+                    oa.outL = d_outL;
+                    oa.outR = d_outR;
+                    oa.ptab = d_ptab;
+                    oa.pstride = pstride;
+                    oa.cring = e->d_cring;
+                    oa.rc = e->rc;
+                    oa.tabs0 = (int64_t)st.ctx.t0;
+                    oa.predelay = (int64_t)st.ctx.predelay;
+                    oa.n_ref = (int64_t)e->cfg.n_ref;
+                    oa.b0 = make_retired(e).b0;
+                    oa.compat = (int)e->cfg.compat;
+                    oa.pm = e->pm;
+                    oa.T = T;
+                    oa.out_from = head;
+                    oa.wet_head = head;
+                    oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));  // what later calls and a predelay change can reach
+                    stored.out_from = head;
                 }
-                launch_inv(e, mo, b, inv_stream, to_wet, mo.corr_terms_done ? &cf : nullptr, &fix_done);
-                if (mo.corr_terms_done) {
-                    mc_engine::BatchCtx& stored = e->pipe[(e->pipe_head + e->pipe_count) % kPipe];
-                    stored.corr_terms_done = true;
-                    stored.corr_fix_done = fix_done;
-                }
+                launch_inv(e, mo, b, inv_stream, to_wet, fuse ? &oa : nullptr);
+                if (mo.corr_done) stored.corr_done = true;
             }
             if (piped && h == 0 && count < e->stream_threshold) {
                 // both parts would use the streaming kernel's partial buffer: the second waits for the first's reader
@@ -1349,7 +1393,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
         // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
         const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
-        if (!ctx.corr_terms_done) {  // (on the headline path both steps rode along with the front half's launches)
+        if (!ctx.corr_done) {  // (on the headline path they rode along with the front half's launches)
             CorrArgs ca;
             std::memset(&ca, 0, sizeof(ca));
             ca.sums = d_sums;
@@ -1368,10 +1412,10 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             ca.need_b0 = ctx.need_b0;
             ca.nchunks = nchunks;
             hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
+            if (nchunks > 1)  // a single chunk adds its base itself
+                hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
+                                   e->d_ctot);
         }
-        if (nchunks > 1 && !ctx.corr_fix_done)  // a single chunk adds its base itself
-            hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
-                               e->d_ctot);
         const bool piped = e->pipelined && !lin_sum && !publish;
         hipStream_t ps = e->stream;
         if (piped) {  // k_post follows this batch's inverse transforms on the post stream, after the prefix sums
@@ -1380,9 +1424,12 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             ps = e->post_stream;
         }
         const TailDrop td = make_taildrop(e, ctx.vir, ctx.predelay);
-        hipLaunchKernelGGL(td.on ? k_post<true> : k_post<false>, dim3((ctx.count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
+        // the front half finished blocks >= out_from itself: only the blocks the predelay fills from the previous batch remain
+        const int post_count = ctx.out_from >= 0 ? ctx.out_from : ctx.count;
+        if (post_count > 0)
+        hipLaunchKernelGGL(td.on ? k_post<true> : k_post<false>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
-                           e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first, ctx.count,
+                           e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first, post_count,
                            ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
                            td, e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
                            publish ? ++e->flag_seq : 0u, e->d_done_ctr);
@@ -1784,7 +1831,7 @@ int process_host_staged(mc_engine* e, const float* in1, const float* in2, float*
         std::memcpy(e->h_io + 1 * cap, in2 + off, bytes);
         HIP_TRY(hipMemcpyAsync(e->d_io[0], e->h_io + 0 * cap, bytes, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->d_io[1], e->h_io + 1 * cap, bytes, hipMemcpyHostToDevice, e->stream));
-        int rc = run_front(e, e->d_io[0], e->d_io[1], n, nullptr, 0, n);
+        int rc = run_front(e, e->d_io[0], e->d_io[1], n, nullptr, 0, n, e->d_io[2], e->d_io[3]);
         if (rc) return rc;
         rc = run_back(e, e->d_io[0], e->d_io[1], nullptr, e->d_io[2], e->d_io[3], n);
         if (!rc) rc = fence_post(e);
@@ -1831,7 +1878,7 @@ int process_host_pinned(mc_engine* e, const float* in1, const float* in2, float*
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
         if (k >= 3) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_d2h[b], 0));
-        int rc = run_front(e, d[0], d[1], n, nullptr, 0, n);
+        int rc = run_front(e, d[0], d[1], n, nullptr, 0, n, d[2], d[3]);
         if (rc) return rc;
         rc = run_back(e, d[0], d[1], nullptr, d[2], d[3], n);
         if (!rc) rc = fence_post(e);
@@ -2132,6 +2179,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_wet, sizeof(float) * 2 * (size_t)e->wr));
     ENG_TRY(hipMalloc(&e->d_cring, sizeof(double) * 4 * (size_t)e->rc));
     ENG_TRY(hipMalloc(&e->d_ctot, sizeof(double) * 4 * (size_t)((e->Tmax + 255) / 256 + 1)));
+    ENG_TRY(hipMalloc(&e->d_cflag, sizeof(unsigned) * (size_t)((e->Tmax + 255) / 256 + 2)));
+    ENG_TRY(hipMemset(e->d_cflag, 0, sizeof(unsigned) * (size_t)((e->Tmax + 255) / 256 + 2)));
+    e->d_cticket = e->d_cflag + (e->Tmax + 255) / 256 + 1;
     e->rr = (int)next_pow2(cfg->n_ref);
     ENG_TRY(hipMalloc(&e->d_res_mac, sizeof(float) * 2 * (size_t)e->rr));
     ENG_TRY(hipMalloc(&e->d_res_fix, sizeof(float) * 2 * (size_t)e->rr));
@@ -2178,6 +2228,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
+    if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
@@ -2246,6 +2297,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_wet);
     (void)hipFree(e->d_cring);
     (void)hipFree(e->d_ctot);
+    (void)hipFree(e->d_cflag);
     (void)hipFree(e->d_done_ctr);
     (void)hipFree(e->d_res_mac);
     (void)hipFree(e->d_res_fix);
@@ -2463,7 +2515,7 @@ int mc_process_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
     if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
-    int rc = run_front(e, d_in1, d_in2, T, nullptr, 0, T);
+    int rc = run_front(e, d_in1, d_in2, T, nullptr, 0, T, d_outL, d_outR);
     if (rc) return rc;
     return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
 }

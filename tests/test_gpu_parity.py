@@ -1795,3 +1795,66 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
         err = rms(outs[-1] - want)
         assert err <= RMS_TOL, f"park={park}: rms {err:.3e}"
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("predelay", [0, 64, 300, 301, 2047, 8192])
+def test_output_finished_by_the_inverse_transforms(oracle_mod, gpu_lib, monkeypatch, predelay):
+    """Whole batches on one engine with no Q8 pass and no retired predelay epoch: the inverse-transform launches
+    (k_inv_wet<true>) finish the output themselves - Q1/Q2 window sums, clamp, dry mix, shifted by the predelay - and
+    k_post only fills the head the predelay reaches back for; the Q1/Q2 prefix sums ride along with k_g2_mac in one pass.
+    Same samples as the k_post route (MCCONV_FUSE_OUT=0, prefix sums as two launches) and as the oracle, for predelays
+    that are and are not multiples of four frames, batches shorter than the predelay, a device-buffer and a host-buffer
+    call, and a parameter change between batches (conv.cu:89-100, 126-140, 411-427)."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    dev = torch.device("cuda:0")
+    n_ref = 131072
+    irs = [make_ir(88200, seed=11, norm=0.08), make_ir(70000, seed=13, norm=0.08)]
+    runs = (1200, 3, 1500, 40, 1024, 1233)  # 3 and 40 blocks: shorter than the longest predelay's reach
+    nb = sum(runs)
+    x = make_input(nb * 256)
+    x[0] += 0.05  # DC and an alternating component: the Q1/Q2 sums matter
+    x[1, ::2] += 0.04
+    p0, p1 = dict(BASE, predelay=predelay, wet=0.6, panDry=0.3), dict(BASE, select=1, level=0.9, panWet=-0.4)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MCCONV_FUSE_OUT", fuse)
+        monkeypatch.setenv("MCCONV_CORR_RIDE", fuse)
+        monkeypatch.setenv("MCCONV_FFT2", "1")
+        monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
+        c = _conv(fftSize=n_ref, max_batch=2048)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        out = np.zeros((2, nb * 256), np.float32)
+        o = 0
+        for k, n in enumerate(runs):
+            s = slice(o * 256, (o + n) * 256)
+            if k == 2:  # dry gains change between batches (the wet path keeps its gains: no cross-fade restarts)
+                c.cc[0].value.update(dry=0.25, panDry=-0.5)
+            if k % 2 == 0:  # device buffers
+                d_in = torch.from_numpy(x[:, s].copy()).to(dev)
+                d_out = torch.full((2, n * 256), float("nan"), device=dev)
+                c.process_device(d_in[0].data_ptr(), d_in[1].data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), n)
+                c.sync()
+                out[:, s] = d_out.cpu().numpy()
+            else:
+                c.process(x[0, s], x[1, s], out[:, s])
+            o += n
+        outs.append(out)
+        c.close()
+    assert np.isfinite(outs[0]).all()
+    assert rms(outs[0] - outs[1]) <= 1e-7, f"finished by k_inv_wet vs by k_post: rms {rms(outs[0] - outs[1]):.3e}"
+    u = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+    apply_params(u, p0, p1, True)
+    nchk, nchg = 1300, runs[0] + runs[1]  # the first two batches and the start of the third (the oracle steps block by block)
+    want = np.zeros((2, nchk * 256))
+    want[:, :nchg * 256] = u.process(x[0, :nchg * 256], x[1, :nchg * 256])
+    u.set(0, dry=0.25, panDry=-0.5)
+    want[:, nchg * 256:] = u.process(x[0, nchg * 256:nchk * 256], x[1, nchg * 256:nchk * 256])
+    err = rms(outs[0][:, :nchk * 256] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e}"
