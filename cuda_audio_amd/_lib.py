@@ -40,7 +40,8 @@ class McConfig(C.Structure):
         ("precision", C.c_uint32),
         ("period", C.c_uint32),
         ("pipeline", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("form", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -21,6 +21,7 @@
 
 #include "../../include/mcconv.h"
 #include "kernels.hip.h"
+#include "singlefft.hip.h"
 
 namespace {
 
@@ -64,6 +65,7 @@ struct IrEntry {
     float2* d_G2 = nullptr;  // second-level spectra for the fused 8192-point form [2 ch][257 rows][G2_N]
     bool g2_valid = false;
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
+    float2* d_S = nullptr;   // single-transform form (mc_config.form = 1): [H_L | H_R], n_ref / 2 bins each
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
     uint64_t taps = 0;
@@ -72,6 +74,7 @@ struct IrEntry {
 };
 
 }  // namespace
+
 
 struct BatchCtx {
     int T = 0;
@@ -121,9 +124,26 @@ struct JackPre {
     int carried_vir[2];          // ... for this IR pair
 };
 
+// state of the single-transform form (singlefft.hip.h / singlefft_host.hip.h)
+struct SfState {
+    int N = 0, M = 0, AT = 1;
+    float2* d_live = nullptr;  // [half][ch][N/2] live IR spectra (the reference's irFFT, conv.h:72)
+    float2* d_X = nullptr;     // [2][N/2] X1, X2
+    float2* d_W = nullptr;     // [N] packed output spectrum
+    float2* d_T = nullptr;     // [512][M] between the inverse passes; IR preparation: the packed taps, then U
+    float2* d_Z = nullptr;     // [N] IR preparation
+    float* d_acc = nullptr;    // [ch][N] accumulators (conv.h:74 residual): a ring, `base` = slot of the next output frame
+    unsigned* d_ctr = nullptr;
+    unsigned base = 0;
+    float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // staging of host-buffer batches, io_cap frames each
+    size_t io_cap = 0;
+    size_t lds_bytes = 0;
+};
+
 struct mc_engine {
     mc_config cfg;
     int device = 0;
+    SfState* sf = nullptr;  // != null: the engine runs the reference's single-transform form (singlefft.hip.h)
     hipStream_t own_stream = nullptr, stream = nullptr;
     int Tcap = 0;  // blocks the scratch buffers and rings are sized for: >= Tmax, and enough to re-render history in few launches
     int Tmax = 0, Pcap = 0, Pstride = 0, ring = 0, sr = 0, wr = 0, rc = 0, nchunk = 2, Tstream = 0;
@@ -2056,6 +2076,9 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
 
 }  // namespace
 
+#include "singlefft_host.hip.h"
+
+
 extern "C" {
 
 uint32_t mc_abi_version(void) { return MC_ABI_VERSION; }
@@ -2148,6 +2171,33 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
 
     ENG_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
+    {
+        const char* fm = std::getenv("MCCONV_FORM");  // lets an unmodified host pick the form: "single" / "partitioned"
+        if (fm && !std::strcmp(fm, "single")) e->cfg.form = 1;
+        else if (fm && !std::strcmp(fm, "partitioned")) e->cfg.form = 0;
+    }
+    if (e->cfg.form > 1) {
+        mc_destroy(e);
+        return fail(MC_ERR_ARG, "mc_config.form must be 0 (partitioned) or 1 (single transform)");
+    }
+    if (e->cfg.form == 1) {  // the reference's own shape: none of the partitioned engine's state
+        ENG_TRY(hipMalloc(&e->d_tw, sizeof(float2) * FFT_N));
+        {
+            std::vector<float2> tw;
+            host_twiddles(tw);
+            ENG_TRY(hipMemcpy(e->d_tw, tw.data(), sizeof(float2) * FFT_N, hipMemcpyHostToDevice));
+        }
+        e->Thost = 4;  // the mapped buffer holds one period
+        ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
+        ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
+        int rc = sf_create(e);
+        if (rc) {
+            mc_destroy(e);
+            return rc;
+        }
+        *out = e;
+        return MC_OK;
+    }
     ENG_TRY(hipMalloc(&e->d_fdl, sizeof(float4) * (size_t)MC_NB * e->ring));
     if (e->half) ENG_TRY(hipMalloc(&e->d_fdl16, sizeof(uint2) * (size_t)MC_NB * e->ring));
     ENG_TRY(hipMalloc(&e->d_slotgain, sizeof(float4) * (size_t)MC_MAXV * e->ring));
@@ -2260,6 +2310,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipSetDevice(e->device);
     unpark(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    sf_free(e);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H) (void)hipFree(e->irs[i].d_H);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
@@ -2337,7 +2388,7 @@ void mc_destroy(mc_engine* e) {
 int mc_reset(mc_engine* e) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
-    return zero_state(e);
+    return e->sf ? sf_zero(e) : zero_state(e);
 }
 
 int mc_set_period(mc_engine* e, uint32_t nframes) {
@@ -2348,7 +2399,7 @@ int mc_set_period(mc_engine* e, uint32_t nframes) {
     if (pm == e->pm) return MC_OK;
     HIP_TRY(hipSetDevice(e->device));
     e->pm = pm;
-    return zero_state(e);  // the per-call semantics change: start from the cold state
+    return e->sf ? sf_zero(e) : zero_state(e);  // the per-call semantics change: start from the cold state
 }
 
 int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uint64_t nframes) {
@@ -2358,6 +2409,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (nframes >= e->cfg.n_ref) return fail(MC_ERR_ARG, "nframes >= n_ref");
     if (frames == 0) return fail(MC_ERR_ARG, "empty IR");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->sf) return sf_load_ir(e, idx, lr, frames, nframes);
     const uint64_t n = std::min<uint64_t>(frames, e->cfg.n_ref - nframes);  // conv.cu:239
     const int P = (int)((n + MC_B - 1) / MC_B);
     if (P > e->Pcap) return fail(MC_ERR_ARG, "IR needs %d partitions, engine capacity is %d", P, e->Pcap);
@@ -2427,7 +2479,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
 int mc_num_irs(const mc_engine* e) { return e ? e->nirs : 0; }
 
 int mc_ir_info(const mc_engine* e, uint64_t idx, double out[6]) {
-    if (!e || !out || idx >= (uint64_t)kMaxIrs || !e->irs[idx].d_H) return fail(MC_ERR_ARG, "IR %llu not loaded", (unsigned long long)idx);
+    if (!e || !out || idx >= (uint64_t)kMaxIrs || !(e->irs[idx].d_H || e->irs[idx].d_S)) return fail(MC_ERR_ARG, "IR %llu not loaded", (unsigned long long)idx);
     for (int i = 0; i < 4; i++) out[i] = e->irs[idx].sums[i];
     out[4] = (double)e->irs[idx].taps;
     out[5] = (double)e->irs[idx].P;
@@ -2483,7 +2535,7 @@ int mc_process(mc_engine* e, const float* in1, const float* in2, float* outL, fl
     // 256-frame periods take the fused single-block path; 512 / 1024 run as one small zero-copy batch
     // (partition shards keep the batch kernels: their low partitions are not the IR's first ones)
     const bool whole_ir = e->cfg.part_begin == 0 && e->cfg.part_end == 0;
-    int rc = e->pm == 1 ? process_one(e, in1, in2, outL, outR)
+    int rc = e->sf ? sf_process(e, in1, in2, outL, outR) : e->pm == 1 ? process_one(e, in1, in2, outL, outR)
                         : (whole_ir ? process_period_fused(e, in1, in2, outL, outR) : process_period(e, in1, in2, outL, outR));
     if (rc) return rc;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2508,6 +2560,7 @@ void mc_host_free(void* p) {
 int mc_process_batch(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, uint64_t nblocks) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->sf) return sf_batch_host(e, in1, in2, outL, outR, (int)std::min<uint64_t>(nblocks, 1u << 30));
     return process_host(e, in1, in2, outL, outR, (int)std::min<uint64_t>(nblocks, 1u << 30));
 }
 
@@ -2515,6 +2568,7 @@ int mc_process_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
     if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (e->sf) return sf_batch_device(e, d_in1, d_in2, d_outL, d_outR, T);
     int rc = run_front(e, d_in1, d_in2, T, nullptr, 0, T, d_outL, d_outR);
     if (rc) return rc;
     return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
@@ -2525,6 +2579,7 @@ int mc_process_batch_slice_device(mc_engine* e, const float* d_in1, const float*
     if (!e || !d_in1 || !d_in2 || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (e->sf) return fail(MC_ERR_ARG, "the single-transform form has no block slices");
     if (first > (uint64_t)T || count > (uint64_t)T) return fail(MC_ERR_ARG, "slice outside the batch");
     int rc = run_front(e, d_in1, d_in2, T, nullptr, (int)first, (int)count);
     if (rc) return rc;
@@ -2535,12 +2590,14 @@ int mc_partial_batch_device(mc_engine* e, const float* d_in1, const float* d_in2
     if (!e || !d_in1 || !d_in2 || !d_partial) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (e->sf) return fail(MC_ERR_ARG, "the single-transform form has no partition shards");
     return run_front(e, d_in1, d_in2, T, d_partial, 0, T);
 }
 
 int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2, const float* d_wet_sum, float* d_outL,
                            float* d_outR, uint64_t nblocks) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
+    if (e->sf) return fail(MC_ERR_ARG, "the single-transform form has no partition shards");
     const bool want_out = d_outL || d_outR || d_wet_sum;
     if (want_out && (!d_in1 || !d_in2 || !d_wet_sum || !d_outL || !d_outR)) return fail(MC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
@@ -2628,6 +2685,7 @@ int mc_get_kernel_stats(mc_engine* e, mc_kernel_stats* out, int reset) {
 uint64_t mc_algorithmic_bytes_per_block(const mc_engine* e) {
     // 4 IR paths + 2 delay-line inputs, P partitions, 256 bins x 8 B
     if (!e) return 0;
+    if (e->sf) return 24ull * e->cfg.n_ref;  // four half spectra (4 N/2 x 8 B) + the input window (2 N x 4 B), per call
     mc_engine* m = const_cast<mc_engine*>(e);
     std::lock_guard<std::mutex> lk(m->pmu);
     const IrEntry& a = e->irs[e->cc[0].select % kMaxIrs];
@@ -2644,6 +2702,7 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
     mc_engine* m = const_cast<mc_engine*>(e);
     std::lock_guard<std::mutex> lk(m->pmu);
     at_most = std::min<uint64_t>(at_most, (uint64_t)e->Tmax);
+    if (e->sf) return at_most - at_most % (uint64_t)e->pm;
     int pmax = 0;
     for (int i = 0; i < kMaxIrs; i++)
         if (e->irs[i].d_H) pmax = std::max(pmax, round_up(e->irs[i].P, 16));
@@ -2665,6 +2724,19 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
 int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off, uint64_t bytes, uint64_t dims[4]) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->sf) {  // single-transform form: 0 = an IR's spectra [H_L | H_R] (float2, n_ref / 2 bins each), 4 = the accumulators [2][n_ref]
+        if (dims) dims[0] = dims[1] = dims[3] = e->cfg.n_ref, dims[2] = (uint64_t)e->Tmax;
+        if (!dst || !bytes) return MC_OK;
+        const char* src = nullptr;
+        uint64_t cap = 0;
+        if (which == 0 && idx < (uint64_t)kMaxIrs && e->irs[idx].d_S) src = (const char*)e->irs[idx].d_S, cap = sizeof(float2) * e->cfg.n_ref;
+        else if (which == 4) src = (const char*)e->sf->d_acc, cap = sizeof(float) * 2 * e->cfg.n_ref;
+        else return fail(MC_ERR_ARG, "nothing to read for item %d in the single-transform form", which);
+        if (off > cap || bytes > cap - off) return fail(MC_ERR_ARG, "read outside the buffer");
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy(dst, src + off, bytes, hipMemcpyDeviceToHost));
+        return MC_OK;
+    }
     if (dims) {
         dims[0] = (uint64_t)e->Pstride;
         dims[1] = (uint64_t)e->ring;

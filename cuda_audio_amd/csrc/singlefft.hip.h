@@ -1,0 +1,301 @@
+// singlefft.hip.h — the path in the reference's OWN shape (mc_config.form = 1; BASELINE config 2, SURVEY §8(d)
+// "Config 2"): one n_ref-point transform per call instead of 256-tap partitions.  Per call of nframes frames
+// (Convolution::onProcess, conv.cu:287-466):
+//
+//   z = in1 + j in2, zero padded to N            conv.cu:35-45, 321-328
+//   live IR spectra += (wet b - live) / (vsteps + 5)   f_interpolate, conv.cu:15-32, 339-353 - literally, per bin
+//   Z = FFT_N(z); X1, X2 = two-for-one split     conv.cu:367, f_unpackC22R :47-73 with its s == 0 shortcut (Q1) and
+//                                                the N/2 entry that is never written (Q2)
+//   Y_c = (X1 L_0c s_0c + X2 L_1c s_1c)          f_pointwiseMultiplyAndScale, conv.cu:102-123, 392-401 (true product)
+//   y_c = IFFT_N(Y_c)                            conv.cu:403-408
+//   acc_c[s] = clamp(acc_c[s] + y_c[s - predelay]), s < N     f_pointwiseAdd, conv.cu:89-100 - the RUNNING accumulator
+//                                                is clamped (Q4) and what the shift pushes past N is dropped (Q8)
+//   out = acc[0 .. nframes) + dry mix            f_addDryInterleaved, conv.cu:126-140, 418-427
+//   acc slides by nframes                        conv.cu:440-451 (here: a ring of N slots, the origin moves)
+//
+// Differences from a literal translation, none of which changes a sample:
+//   * only the REAL part of the reference's complex accumulators is ever heard (.x, conv.cu:431-437) and the imaginary
+//     part never feeds back into it, so Y_L and Y_R go through ONE packed inverse transform (their Hermitian parts:
+//     Re Y[0], 0 at N/2) and the accumulators are real;
+//   * the input has nframes <= 1024 non-zero samples: with N = 512 M, n = a + 512 b, k = d + M c the forward
+//     transform is M transforms of 512 points of the twiddled input (pruned four-step: the pass over b has one or two
+//     non-zero terms, folded into the input), each on one wavefront (fft512_wave);
+//   * spectra are kept for bins 0 .. N/2 - 1 only; the mirrored half of the reference's buffers is implied.
+// The inverse is the plain four-step: 512-point transforms over c (k_sf_inv1), twiddle, M-point transforms over d in
+// LDS (radix-2 Stockham, k_sf_inv2), whose epilogue accumulates, clamps and - last workgroup out - emits the period.
+// IR preparation (Convolution::prepare, conv.cu:207-253) is the same four-step forward on the packed L + jR taps
+// (k_sf_ir_cols, k_sf_ir_rows) and the split (k_sf_ir_unpack).
+//
+// Bytes per call at N = 131072 (all of it lives in the 256 MB last-level cache): live spectra 2 MiB read + 2 MiB
+// written, selected IRs 2 MiB, X 1 MiB w + r, packed Y 1 MiB w + r, pass-1 result 1 MiB w + r, accumulators 1 MiB r + w
+// = 14 MiB; SURVEY §8(d) counts 3 MiB algorithmic (IR half-spectra + input window).
+#pragma once
+
+#define SF_ROWS 8  // 512-point transforms (wavefronts) per workgroup of the row kernels
+
+struct SfCall {
+    const float *in1, *in2;  // nframes samples each
+    float *outL, *outR;
+    int nframes;
+    int pd;                  // predelay of half 0 (conv.cu:412,415)
+    float wet[2], div[2];    // f_interpolate: live += (wet b - live) / div, div = vsteps + 5
+    const float2* b[2];      // spectra of the selected IRs: [H_L | H_R], N/2 bins each
+    float sc[2][2];          // [c][i] = pan_c(panWet_i) level_i / N       (conv.cu:386-401)
+    float dry[2][2];         // [c][i] = dry_i pan_c(panDry_i) level_i     (conv.cu:418-427)
+    unsigned base;           // accumulator slot of this call's output frame 0
+};
+
+__device__ __forceinline__ float2 sf_cis(unsigned ph, int N, float sign) {  // exp(sign 2 pi i ph / N), ph < N
+    float sn, cs;
+    sincospif(sign * 2.0f * (float)ph / (float)N, &sn, &cs);
+    return make_float2(cs, sn);
+}
+
+// ---------------------------------------------------------------------------
+// S1: X1, X2 for bins s = d + M c < N/2 from the period's nframes samples.
+// One wavefront per d and input.  grid = M / SF_ROWS, block = 64 SF_ROWS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * SF_ROWS) void k_sf_fwd(SfCall C, int N, int M, float2* __restrict__ X,
+                                                         const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
+    load_twiddles(s_tw, g_tw);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d0 = blockIdx.x * SF_ROWS, d = d0 + wave;
+    float2 dc = make_float2(0.f, 0.f);  // {S1, S2} (d == 0): the split's s == 0 shortcut puts Z[0] into X1[0] (Q1)
+    for (int i = 0; i < 2; i++) {
+        const float* in = i ? C.in2 : C.in1;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
+                const float x = in[n];
+                const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
+                acc.x += x * w.x;
+                acc.y += x * w.y;
+            }
+            v[r] = acc;
+        }
+        fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
+        __syncthreads();
+        if (i == 0) dc.x = s_fft[0][0].x;  // (d0 == 0: wave 0 holds d = 0, whose entry 0 is the sum of the samples)
+        else dc.y = s_fft[0][0].x;
+        // bins d0 + di + M c, c < 256: SF_ROWS consecutive bins per c
+        for (int idx = threadIdx.x; idx < SF_ROWS * 256; idx += 64 * SF_ROWS) {
+            const int di = idx % SF_ROWS, c = idx / SF_ROWS;
+            const int s = d0 + di + M * c;
+            if (s) X[(size_t)i * (N / 2) + s] = s_fft[di][c];
+        }
+        __syncthreads();
+    }
+    if (d0 == 0 && threadIdx.x == 0) {
+        X[0] = dc;                                   // X1[0] = Z[0] = S1 + j S2
+        X[(size_t)(N / 2)] = make_float2(0.f, 0.f);  // X2[0] = 0
+    }
+}
+
+// ---------------------------------------------------------------------------
+// S2: per bin s < N/2 - the four live spectra take their step towards wet x the
+// selected IR, the two output spectra are formed and packed for one inverse
+// transform: W = Yh_L + j Yh_R with Yh the Hermitian part (Re at s = 0, 0 at N/2).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sf_mac(SfCall C, int N, const float2* __restrict__ X, float2* __restrict__ live,
+                                                float2* __restrict__ W) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int H = N / 2;
+    if (s >= H) return;
+    const float2 x[2] = {X[s], X[(size_t)H + s]};
+    float2 y[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float2* lp = live + (size_t)(i * 2 + c) * H + s;
+            const float2 va = *lp, b = C.b[i][(size_t)c * H + s];
+            const float2 vb = make_float2(b.x * C.wet[i], b.y * C.wet[i]);
+            const float2 vv = make_float2(va.x + (vb.x - va.x) / C.div[i], va.y + (vb.y - va.y) / C.div[i]);
+            *lp = vv;
+            const float2 p = make_float2(x[i].x * vv.x - x[i].y * vv.y, x[i].x * vv.y + x[i].y * vv.x);
+            y[c].x += p.x * C.sc[c][i];
+            y[c].y += p.y * C.sc[c][i];
+        }
+    if (s == 0) {
+        W[0] = make_float2(y[0].x, y[1].x);
+        W[H] = make_float2(0.f, 0.f);
+    } else {
+        W[s] = make_float2(y[0].x - y[1].y, y[0].y + y[1].x);       // Y_L + j Y_R
+        W[N - s] = make_float2(y[0].x + y[1].y, -y[0].y + y[1].x);  // conj(Y_L) + j conj(Y_R)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// S3: inverse, pass 1 - for each d: 512 points over c of W[d + M c] -> a,
+// times exp(+2 pi i a d / N), to T[a M + d].  grid = M / SF_ROWS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * SF_ROWS) void k_sf_inv1(int N, int M, const float2* __restrict__ W, float2* __restrict__ Tm,
+                                                          const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
+    __shared__ float2 s_in[SF_ROWS][FFT_N + 1];
+    load_twiddles(s_tw, g_tw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d0 = blockIdx.x * SF_ROWS;
+    for (int idx = threadIdx.x; idx < SF_ROWS * FFT_N; idx += 64 * SF_ROWS) {
+        const int di = idx % SF_ROWS, c = idx / SF_ROWS;
+        s_in[di][c] = W[(size_t)d0 + di + (size_t)M * c];
+    }
+    __syncthreads();
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = s_in[wave][lane + 64 * r];
+    fft512_wave<+1, false>(v, s_fft[wave], s_tw, lane);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SF_ROWS * FFT_N; idx += 64 * SF_ROWS) {
+        const int di = idx % SF_ROWS, a = idx / SF_ROWS;
+        const float2 val = s_fft[di][a];
+        const float2 w = sf_cis(((unsigned)a * (unsigned)(d0 + di)) & (unsigned)(N - 1), N, +1.f);
+        Tm[(size_t)a * M + d0 + di] = make_float2(val.x * w.x - val.y * w.y, val.x * w.y + val.y * w.x);
+    }
+}
+
+// M-point transforms of nseq sequences (contiguous, M entries each) in LDS: radix-2 Stockham, log2 M passes between
+// the two buffers; tw[m] = exp(SIGN 2 pi i m / M), m < M/2.  Returns the buffer that holds the result (natural order).
+__device__ __forceinline__ float2* sf_fft_lds(float2* src, float2* dst, const float2* tw, int M, int nseq) {
+    const int half = M >> 1;
+    int lgh = 0;
+    while ((1 << lgh) < half) lgh++;
+    for (int p = 1, lgp = 0; p < M; p <<= 1, lgp++) {
+        for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
+            const int q = idx >> lgh, j = idx & (half - 1);
+            const int k = j & (p - 1);
+            const float2 u0 = src[q * M + j], x1 = src[q * M + j + half];
+            const float2 w = tw[k << (lgh - lgp)];  // exp(SIGN pi i k / p)
+            const float2 u1 = make_float2(x1.x * w.x - x1.y * w.y, x1.x * w.y + x1.y * w.x);
+            const int j0 = ((j - k) << 1) + k;
+            dst[q * M + j0] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            dst[q * M + j0 + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+        __syncthreads();
+        float2* t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+// ---------------------------------------------------------------------------
+// S4: inverse, pass 2 - for AT consecutive a: M points over d of T[a M + d] -> b,
+// y[n = a + 512 b] = {y_L, y_R}; acc[(base + n + pd) mod N] = clamp(acc + y) for
+// n + pd < N.  The last workgroup to finish emits the period: out = acc[base + s]
+// + dry mix for s < nframes, and clears those slots (they become the far end of
+// the accumulator: the reference shifts zeros in, conv.cu:440-451).
+// grid = 512 / AT, block = 256, dynamic LDS = (2 AT M + M / 2) float2.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT, const float2* __restrict__ Tm,
+                                                 float* __restrict__ acc, unsigned* __restrict__ done_ctr) {
+    extern __shared__ float2 sf_sm[];
+    float2* bufA = sf_sm;
+    float2* bufB = sf_sm + AT * M;
+    float2* tw = sf_sm + 2 * AT * M;
+    const int a0 = blockIdx.x * AT;
+    for (int m = threadIdx.x; m < M / 2; m += 256) tw[m] = sf_cis((unsigned)m, M, +1.f);
+    for (int idx = threadIdx.x; idx < AT * M; idx += 256) bufA[idx] = Tm[(size_t)a0 * M + idx];
+    __syncthreads();
+    const float2* y = sf_fft_lds(bufA, bufB, tw, M, AT);
+    for (int idx = threadIdx.x; idx < AT * M; idx += 256) {
+        const int ai = idx % AT, b = idx / AT;
+        const unsigned s = (unsigned)(a0 + ai + FFT_N * b) + (unsigned)C.pd;
+        if (s < (unsigned)N) {
+            const float2 v = y[ai * M + b];
+            const unsigned at = (C.base + s) & (unsigned)(N - 1);
+            acc[at] = fminf(fmaxf(acc[at] + v.x, -1.f), 1.f);
+            acc[(size_t)N + at] = fminf(fmaxf(acc[(size_t)N + at] + v.y, -1.f), 1.f);
+        }
+    }
+    __shared__ unsigned s_last;
+    __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int s = threadIdx.x; s < C.nframes; s += 256) {
+        const unsigned at = (C.base + (unsigned)s) & (unsigned)(N - 1);
+        // (other workgroups wrote these slots: read past this CU's vector cache)
+        const float wl = __hip_atomic_load(acc + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float wr = __hip_atomic_load(acc + (size_t)N + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float x1 = C.in1[s], x2 = C.in2[s];
+        C.outL[s] = wl + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
+        C.outR[s] = wr + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
+        acc[at] = 0.f;
+        acc[(size_t)N + at] = 0.f;
+    }
+    if (threadIdx.x == 0) *done_ctr = 0;
+}
+
+// ---------------------------------------------------------------------------
+// IR preparation (conv.cu:207-253): Z = FFT_N(L + j R) by the four-step forward
+// transform, then the two-for-one split.
+//   k_sf_ir_cols: for each a: M points over b of z[a + 512 b] -> d, times exp(-2 pi i a d / N), to U[d 512 + a]
+//   k_sf_ir_rows: for each d: 512 points over a of U[d 512 + a] -> c, to Z[d + M c]
+//   k_sf_ir_unpack: H_L[s], H_R[s] for s < N/2 from Z[s], Z[N - s] (s == 0: the shortcut of conv.cu:53; Q1)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sf_ir_cols(int N, int M, int AT, const float2* __restrict__ z, float2* __restrict__ U) {
+    extern __shared__ float2 sf_sm[];
+    float2* bufA = sf_sm;
+    float2* bufB = sf_sm + AT * M;
+    float2* tw = sf_sm + 2 * AT * M;
+    const int a0 = blockIdx.x * AT;
+    for (int m = threadIdx.x; m < M / 2; m += 256) tw[m] = sf_cis((unsigned)m, M, -1.f);
+    for (int idx = threadIdx.x; idx < AT * M; idx += 256) {
+        const int ai = idx % AT, b = idx / AT;
+        bufA[ai * M + b] = z[(size_t)a0 + ai + (size_t)FFT_N * b];
+    }
+    __syncthreads();
+    const float2* y = sf_fft_lds(bufA, bufB, tw, M, AT);
+    for (int idx = threadIdx.x; idx < AT * M; idx += 256) {
+        const int ai = idx % AT, d = idx / AT;
+        const float2 val = y[ai * M + d];
+        const float2 w = sf_cis(((unsigned)(a0 + ai) * (unsigned)d) & (unsigned)(N - 1), N, -1.f);
+        U[(size_t)d * FFT_N + a0 + ai] = make_float2(val.x * w.x - val.y * w.y, val.x * w.y + val.y * w.x);
+    }
+}
+
+__global__ __launch_bounds__(64 * SF_ROWS) void k_sf_ir_rows(int M, const float2* __restrict__ U, float2* __restrict__ Z,
+                                                             const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
+    load_twiddles(s_tw, g_tw);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d0 = blockIdx.x * SF_ROWS;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = U[(size_t)(d0 + wave) * FFT_N + lane + 64 * r];
+    fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SF_ROWS * FFT_N; idx += 64 * SF_ROWS) {
+        const int di = idx % SF_ROWS, c = idx / SF_ROWS;
+        Z[(size_t)d0 + di + (size_t)M * c] = s_fft[di][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sf_ir_unpack(int N, const float2* __restrict__ Z, float2* __restrict__ Hb) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int H = N / 2;
+    if (s >= H) return;
+    const float2 va = Z[s];
+    float2 vb = va;
+    if (s) {
+        const float2 t = Z[N - s];
+        vb = make_float2(t.x, -t.y);
+    }
+    const float2 la = make_float2(0.5f * (va.x + vb.x), 0.5f * (va.y + vb.y));
+    const float2 dd = make_float2(-0.5f * (va.x - vb.x), -0.5f * (va.y - vb.y));
+    Hb[s] = la;
+    Hb[(size_t)H + s] = make_float2(-dd.y, dd.x);  // times j
+}

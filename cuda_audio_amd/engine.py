@@ -81,7 +81,8 @@ class CC:
 
 class Convolution:
     def __init__(self, name="Conv", fftSize=CONV_DEFAULT_FFTSIZE, *, max_batch=256, device=-1, compat=True,
-                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32", period=256, pipeline=False):
+                 part_begin=0, part_end=0, max_partitions=0, stream_threshold=0, precision="fp32", period=256, pipeline=False,
+                 form="partitioned"):
         self.name = name
         self._L = _lib.load()
         cfg = McConfig()
@@ -96,6 +97,7 @@ class Convolution:
         cfg.precision = {"fp32": 0, "fp16": 1}[precision]
         cfg.period = period
         cfg.pipeline = 1 if pipeline else 0
+        cfg.form = {"partitioned": 0, "single": 1}[form]
         h = C.c_void_p()
         check(self._L.mc_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -78,7 +78,13 @@ typedef struct {
                                the engine's stream, only after mc_fence (or mc_sync); its inputs must stay valid
                                until then.  Other calls drain the pipeline first.  0 = every call is complete in
                                stream order (default). */
-    uint32_t reserved[2];
+    uint32_t form;          /* 0 = uniform-partitioned engine (default).  1 = the path in the reference's own shape
+                               (BASELINE config 2): one n_ref-point transform per call, its live IR spectra stepped bin
+                               by bin (conv.cu:15-32) and an n_ref-long running accumulator clamped at +-1 every call
+                               (conv.cu:89-100) - the same samples while nothing saturates, the reference's samples
+                               beyond.  n_ref <= 1048576, whole IR on one engine, fp32; no slices / shards / pipeline.
+                               The environment variable MCCONV_FORM=single|partitioned overrides the field. */
+    uint32_t reserved;
 } mc_config;
 
 /* mirrors Convolution::CC::value (conv.h:38-49); same defaults via mc_default_params */
