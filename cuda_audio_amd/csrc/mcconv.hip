@@ -138,6 +138,7 @@ struct SfState {
     float* d_io[4] = {nullptr, nullptr, nullptr, nullptr};  // staging of host-buffer batches, io_cap frames each
     size_t io_cap = 0;
     size_t lds_bytes = 0;
+    bool stockham = false;  // MCCONV_SF_STOCKHAM: pass 2 of the inverse through the LDS transform whatever the size
 };
 
 struct mc_engine {
@@ -2724,7 +2725,7 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
 int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off, uint64_t bytes, uint64_t dims[4]) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
-    if (e->sf) {  // single-transform form: 0 = an IR's spectra [H_L | H_R] (float2, n_ref / 2 bins each), 4 = the accumulators [2][n_ref]
+    if (e->sf) {  // single-transform form: 0 = an IR's spectra [H_L | H_R] (float2, n_ref / 2 bins each), 4 = the accumulators [2][512][n_ref / 512]
         if (dims) dims[0] = dims[1] = dims[3] = e->cfg.n_ref, dims[2] = (uint64_t)e->Tmax;
         if (!dst || !bytes) return MC_OK;
         const char* src = nullptr;

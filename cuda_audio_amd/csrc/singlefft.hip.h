@@ -53,46 +53,43 @@ __device__ __forceinline__ float2 sf_cis(unsigned ph, int N, float sign) {  // e
 
 // ---------------------------------------------------------------------------
 // S1: X1, X2 for bins s = d + M c < N/2 from the period's nframes samples.
-// One wavefront per d and input.  grid = M / SF_ROWS, block = 64 SF_ROWS.
+// One wavefront per d and input: waves 0 .. SF_ROWS/2 - 1 take in1, the others in2.
+// grid = 2 M / SF_ROWS, block = 64 SF_ROWS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * SF_ROWS) void k_sf_fwd(SfCall C, int N, int M, float2* __restrict__ X,
                                                          const float2* __restrict__ g_tw) {
+    constexpr int RD = SF_ROWS / 2;  // values of d per workgroup
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
     load_twiddles(s_tw, g_tw);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d0 = blockIdx.x * SF_ROWS, d = d0 + wave;
-    float2 dc = make_float2(0.f, 0.f);  // {S1, S2} (d == 0): the split's s == 0 shortcut puts Z[0] into X1[0] (Q1)
-    for (int i = 0; i < 2; i++) {
-        const float* in = i ? C.in2 : C.in1;
-        float2 v[8];
+    const int i = wave / RD, d0 = blockIdx.x * RD, d = d0 + wave % RD;
+    const float* in = i ? C.in2 : C.in1;
+    float2 v[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            float2 acc = make_float2(0.f, 0.f);
-            for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
-                const float x = in[n];
-                const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
-                acc.x += x * w.x;
-                acc.y += x * w.y;
-            }
-            v[r] = acc;
+    for (int r = 0; r < 8; r++) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
+            const float x = in[n];
+            const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
+            acc.x += x * w.x;
+            acc.y += x * w.y;
         }
-        fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
-        __syncthreads();
-        if (i == 0) dc.x = s_fft[0][0].x;  // (d0 == 0: wave 0 holds d = 0, whose entry 0 is the sum of the samples)
-        else dc.y = s_fft[0][0].x;
-        // bins d0 + di + M c, c < 256: SF_ROWS consecutive bins per c
-        for (int idx = threadIdx.x; idx < SF_ROWS * 256; idx += 64 * SF_ROWS) {
-            const int di = idx % SF_ROWS, c = idx / SF_ROWS;
-            const int s = d0 + di + M * c;
-            if (s) X[(size_t)i * (N / 2) + s] = s_fft[di][c];
-        }
-        __syncthreads();
+        v[r] = acc;
+    }
+    __syncthreads();
+    fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
+    __syncthreads();
+    // bins d0 + di + M c, c < 256, of both inputs: RD consecutive bins per c
+    for (int idx = threadIdx.x; idx < SF_ROWS * 256; idx += 64 * SF_ROWS) {
+        const int w = idx % SF_ROWS, c = idx / SF_ROWS;
+        const int s = d0 + w % RD + M * c;
+        if (s) X[(size_t)(w / RD) * (N / 2) + s] = s_fft[w][c];
     }
     if (d0 == 0 && threadIdx.x == 0) {
-        X[0] = dc;                                   // X1[0] = Z[0] = S1 + j S2
-        X[(size_t)(N / 2)] = make_float2(0.f, 0.f);  // X2[0] = 0
+        // the split's s == 0 shortcut (Q1): X1[0] = Z[0] = S1 + j S2, X2[0] = 0; entry 0 of d = 0 is the sum of the samples
+        X[0] = make_float2(s_fft[0][0].x, s_fft[RD][0].x);
+        X[(size_t)(N / 2)] = make_float2(0.f, 0.f);
     }
 }
 
@@ -186,13 +183,76 @@ __device__ __forceinline__ float2* sf_fft_lds(float2* src, float2* dst, const fl
 }
 
 // ---------------------------------------------------------------------------
-// S4: inverse, pass 2 - for AT consecutive a: M points over d of T[a M + d] -> b,
-// y[n = a + 512 b] = {y_L, y_R}; acc[(base + n + pd) mod N] = clamp(acc + y) for
-// n + pd < N.  The last workgroup to finish emits the period: out = acc[base + s]
-// + dry mix for s < nframes, and clears those slots (they become the far end of
-// the accumulator: the reference shifts zeros in, conv.cu:440-451).
-// grid = 512 / AT, block = 256, dynamic LDS = (2 AT M + M / 2) float2.
+// S4: inverse, pass 2 - for each a: M points over d of T[a M + d] -> b,
+// y[n = a + 512 b] = {y_L, y_R}; acc[slot(n + pd)] = clamp(acc + y) for
+// n + pd < N.  The accumulators are kept in the order this pass produces:
+// slot t = (base + s) mod N lives at [t mod 512][t / 512], so the M results of
+// one a are one (rotated) contiguous row.  The last workgroup to finish emits the
+// period: out = acc[slot(s)] + dry mix for s < nframes, and clears those slots
+// (they become the far end of the accumulator: the reference shifts zeros in,
+// conv.cu:440-451).
+//   k_sf_inv2w (M <= 512): one wavefront per a - the row zero-padded to 512 points,
+//                          U[j] = X[j 512 / M]; grid = 512 / SF_ROWS2, block = 64 SF_ROWS2
+//   k_sf_inv2  (any M)   : AT rows per workgroup, radix-2 Stockham in LDS;
+//                          grid = 512 / AT, block = 256, dynamic LDS = (2 AT M + M / 2) float2
 // ---------------------------------------------------------------------------
+#define SF_ROWS2 4
+
+__device__ __forceinline__ void sf_accumulate(const SfCall& C, int N, int M, int a, int b, float2 v, float* __restrict__ acc) {
+    if ((unsigned)C.pd + (unsigned)a + (unsigned)FFT_N * (unsigned)b >= (unsigned)N) return;  // pushed past the end: dropped (Q8)
+    const unsigned t = C.base + (unsigned)C.pd + (unsigned)a;
+    const size_t at = (size_t)(t & (FFT_N - 1)) * M + (((t >> 9) + (unsigned)b) & (unsigned)(M - 1));
+    acc[at] = fminf(fmaxf(acc[at] + v.x, -1.f), 1.f);
+    acc[(size_t)N + at] = fminf(fmaxf(acc[(size_t)N + at] + v.y, -1.f), 1.f);
+}
+
+// every thread of the workgroup calls this after its last accumulator store
+__device__ __forceinline__ void sf_emit_if_last(const SfCall& C, int N, int M, float* __restrict__ acc, unsigned* __restrict__ done_ctr) {
+    __shared__ unsigned s_last;
+    __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int s = threadIdx.x; s < C.nframes; s += blockDim.x) {
+        const unsigned t = C.base + (unsigned)s;
+        const size_t at = (size_t)(t & (FFT_N - 1)) * M + ((t >> 9) & (unsigned)(M - 1));
+        // (other workgroups wrote these slots: read past this CU's vector cache)
+        const float wl = __hip_atomic_load(acc + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float wr = __hip_atomic_load(acc + (size_t)N + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float x1 = C.in1[s], x2 = C.in2[s];
+        C.outL[s] = wl + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
+        C.outR[s] = wr + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
+        acc[at] = 0.f;
+        acc[(size_t)N + at] = 0.f;
+    }
+    if (threadIdx.x == 0) *done_ctr = 0;
+}
+
+__global__ __launch_bounds__(64 * SF_ROWS2) void k_sf_inv2w(SfCall C, int N, int M, const float2* __restrict__ Tm,
+                                                            float* __restrict__ acc, unsigned* __restrict__ done_ctr,
+                                                            const float2* __restrict__ g_tw) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ float2 s_fft[SF_ROWS2][FFT_WAVE_LDS];
+    load_twiddles(s_tw, g_tw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a = blockIdx.x * SF_ROWS2 + wave;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int d = lane + 64 * r;
+        v[r] = d < M ? Tm[(size_t)a * M + d] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft512_wave<+1, false>(v, s_fft[wave], s_tw, lane);
+    const int R = FFT_N / M;
+    for (int b = lane; b < M; b += 64) sf_accumulate(C, N, M, a, b, s_fft[wave][b * R], acc);
+    sf_emit_if_last(C, N, M, acc, done_ctr);
+}
+
 __global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT, const float2* __restrict__ Tm,
                                                  float* __restrict__ acc, unsigned* __restrict__ done_ctr) {
     extern __shared__ float2 sf_sm[];
@@ -204,37 +264,8 @@ __global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT,
     for (int idx = threadIdx.x; idx < AT * M; idx += 256) bufA[idx] = Tm[(size_t)a0 * M + idx];
     __syncthreads();
     const float2* y = sf_fft_lds(bufA, bufB, tw, M, AT);
-    for (int idx = threadIdx.x; idx < AT * M; idx += 256) {
-        const int ai = idx % AT, b = idx / AT;
-        const unsigned s = (unsigned)(a0 + ai + FFT_N * b) + (unsigned)C.pd;
-        if (s < (unsigned)N) {
-            const float2 v = y[ai * M + b];
-            const unsigned at = (C.base + s) & (unsigned)(N - 1);
-            acc[at] = fminf(fmaxf(acc[at] + v.x, -1.f), 1.f);
-            acc[(size_t)N + at] = fminf(fmaxf(acc[(size_t)N + at] + v.y, -1.f), 1.f);
-        }
-    }
-    __shared__ unsigned s_last;
-    __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int s = threadIdx.x; s < C.nframes; s += 256) {
-        const unsigned at = (C.base + (unsigned)s) & (unsigned)(N - 1);
-        // (other workgroups wrote these slots: read past this CU's vector cache)
-        const float wl = __hip_atomic_load(acc + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float wr = __hip_atomic_load(acc + (size_t)N + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float x1 = C.in1[s], x2 = C.in2[s];
-        C.outL[s] = wl + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
-        C.outR[s] = wr + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
-        acc[at] = 0.f;
-        acc[(size_t)N + at] = 0.f;
-    }
-    if (threadIdx.x == 0) *done_ctr = 0;
+    for (int idx = threadIdx.x; idx < AT * M; idx += 256) sf_accumulate(C, N, M, a0 + idx / M, idx % M, y[idx], acc);
+    sf_emit_if_last(C, N, M, acc, done_ctr);
 }
 
 // ---------------------------------------------------------------------------

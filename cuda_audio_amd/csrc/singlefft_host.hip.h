@@ -42,6 +42,7 @@ inline int sf_create(mc_engine* e) {
     s->M = (int)(N / FFT_N);
     s->AT = std::max(1, std::min(8, 2048 / s->M));
     s->lds_bytes = sizeof(float2) * (size_t)(2 * s->AT * s->M + s->M / 2);
+    s->stockham = std::getenv("MCCONV_SF_STOCKHAM") != nullptr;  // (tests: the LDS transform of the long sizes at a short one)
     HIP_TRY(hipMalloc(&s->d_live, sizeof(float2) * 4 * (size_t)(N / 2)));
     HIP_TRY(hipMalloc(&s->d_X, sizeof(float2) * N));
     HIP_TRY(hipMalloc(&s->d_W, sizeof(float2) * N));
@@ -120,10 +121,13 @@ inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL
             C.dry[c][i] = (float)((double)cc[i].dry * pdry[c] * (double)cc[i].level);
         }
     }
-    hipLaunchKernelGGL(k_sf_fwd, dim3(s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, C, s->N, s->M, s->d_X, e->d_tw);
+    hipLaunchKernelGGL(k_sf_fwd, dim3(2 * s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, C, s->N, s->M, s->d_X, e->d_tw);
     hipLaunchKernelGGL(k_sf_mac, dim3((s->N / 2 + 255) / 256), dim3(256), 0, e->stream, C, s->N, s->d_X, s->d_live, s->d_W);
     hipLaunchKernelGGL(k_sf_inv1, dim3(s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, s->N, s->M, s->d_W, s->d_T, e->d_tw);
-    hipLaunchKernelGGL(k_sf_inv2, dim3(FFT_N / s->AT), dim3(256), s->lds_bytes, e->stream, C, s->N, s->M, s->AT, s->d_T, s->d_acc, s->d_ctr);
+    if (s->M <= FFT_N && !s->stockham)
+        hipLaunchKernelGGL(k_sf_inv2w, dim3(FFT_N / SF_ROWS2), dim3(64 * SF_ROWS2), 0, e->stream, C, s->N, s->M, s->d_T, s->d_acc, s->d_ctr, e->d_tw);
+    else
+        hipLaunchKernelGGL(k_sf_inv2, dim3(FFT_N / s->AT), dim3(256), s->lds_bytes, e->stream, C, s->N, s->M, s->AT, s->d_T, s->d_acc, s->d_ctr);
     s->base = (s->base + (unsigned)nframes) & (unsigned)(s->N - 1);
     e->t_abs += (uint64_t)e->pm;
     return MC_OK;

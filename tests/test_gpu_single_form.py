@@ -65,12 +65,20 @@ def test_ir_spectra_carry_the_split_quirks(oracle_mod, gpu_lib):
     assert got[1, 0] == 0
 
 
-@pytest.mark.parametrize("n_ref,taps,nb", [(4096, 2500, 64), (16384, 14000, 120), (131072, 88200, 40)],
-                         ids=["N4096", "N16384", "config2_N131072"])
-def test_cold_start_and_steady_state(oracle_mod, gpu_lib, n_ref, taps, nb):
+@pytest.mark.parametrize("n_ref,taps,nb,stockham", [(4096, 2500, 64, False), (16384, 14000, 120, False), (16384, 14000, 70, True),
+                                                    (131072, 88200, 40, False), (524288, 441000, 10, False)],
+                         ids=["N4096", "N16384", "N16384_lds_transform", "config2_N131072", "N524288"])
+def test_cold_start_and_steady_state(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, nb, stockham):
     """Cold start (the live spectra ramp up from zero, Q7) into steady state, unequal halves, predelay; the 2 s IR at
-    the reference's default size is BASELINE config 2 (conv.cu:287-466)."""
+    the reference's default size is BASELINE config 2 (conv.cu:287-466).  Sizes above 262144 run the second inverse
+    pass as a radix-2 transform in LDS (k_sf_inv2), the others on one wavefront per row (k_sf_inv2w); the LDS path
+    is also forced at a short size."""
     from cuda_audio_amd.synth import make_input, make_ir
+
+    if stockham:
+        monkeypatch.setenv("MCCONV_SF_STOCKHAM", "1")
+    else:
+        monkeypatch.delenv("MCCONV_SF_STOCKHAM", raising=False)
 
     irs = [make_ir(taps, seed=21, norm=0.3), make_ir(taps - 300, seed=23, norm=0.3)]
     x = make_input(nb * 256, seed=5)

@@ -84,9 +84,11 @@ def test_midi_running_status(host_built):
 
 
 @pytest.mark.gpu
-def test_convolution_class_through_fake_jack(host_built, oracle_mod, tmp_path):
+@pytest.mark.parametrize("form", ["partitioned", "single"])
+def test_convolution_class_through_fake_jack(host_built, oracle_mod, tmp_path, form):
     """The C++ `Convolution` (conv.h surface) driven by the fake JACK server: WAV IRs, public cc[] values,
-    a MIDI controller change mid-stream, output vs the restatement run with the same events."""
+    a MIDI controller change mid-stream, output vs the restatement run with the same events.  MCCONV_FORM=single:
+    the same unmodified host on the engine's single-transform form (the reference's own shape)."""
     from cuda_audio_amd.synth import make_input, make_ir
 
     nb, n_ref = 48, 8192
@@ -105,7 +107,7 @@ def test_convolution_class_through_fake_jack(host_built, oracle_mod, tmp_path):
     cmd = [DEMO, str(n_ref), str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(nb)] + wavs
     cmd += ["--set", "1", "select", "1", "--set", "0", "predelay", "512", "--set", "0", "panWet", "0.5",
             "--cc", "0", "23", str(cc_val), f"@{cc_block}"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MCCONV_FORM=form))
     assert res.returncode == 0, res.stderr + res.stdout
     got = np.fromfile(str(tmp_path / "out.f32"), np.float32).reshape(2, -1)
 
