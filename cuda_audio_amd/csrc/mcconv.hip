@@ -2191,6 +2191,10 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         e->Thost = 4;  // the mapped buffer holds one period
         ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
         ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
+        ENG_TRY(hipHostMalloc(&e->h_flag, 256, hipHostMallocMapped));  // completion word of mc_process
+        ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
+        std::memset(e->h_flag, 0, 256);
+        if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
         int rc = sf_create(e);
         if (rc) {
             mc_destroy(e);

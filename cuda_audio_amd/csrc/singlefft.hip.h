@@ -43,6 +43,8 @@ struct SfCall {
     float sc[2][2];          // [c][i] = pan_c(panWet_i) level_i / N       (conv.cu:386-401)
     float dry[2][2];         // [c][i] = dry_i pan_c(panDry_i) level_i     (conv.cu:418-427)
     unsigned base;           // accumulator slot of this call's output frame 0
+    unsigned* done_flag;     // != null (mapped host memory; outL / outR are too): `seq` is stored once the period is on the host
+    unsigned seq;
 };
 
 __device__ __forceinline__ float2 sf_cis(unsigned ph, int N, float sign) {  // exp(sign 2 pi i ph / N), ph < N
@@ -230,6 +232,13 @@ __device__ __forceinline__ void sf_emit_if_last(const SfCall& C, int N, int M, f
         acc[(size_t)N + at] = 0.f;
     }
     if (threadIdx.x == 0) *done_ctr = 0;
+    if (C.done_flag) {
+        __syncthreads();  // the period's stores have been issued and acknowledged
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the output is on the host
+            __hip_atomic_store(C.done_flag, C.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64 * SF_ROWS2) void k_sf_inv2w(SfCall C, int N, int M, const float2* __restrict__ Tm,

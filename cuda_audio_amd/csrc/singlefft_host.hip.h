@@ -88,7 +88,7 @@ inline int sf_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t fram
 
 // One call of the reference's onProcess on buffers the device can read and write.  The parameters are sampled and the
 // cross-fade counters stepped under the lock, as onProcess does with its public members (conv.cu:339-353).
-inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int nframes) {
+inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int nframes, bool publish = false) {
     SfState* s = e->sf;
     mc_cc_value cc[2];
     {
@@ -111,6 +111,10 @@ inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL
     C.nframes = nframes;
     C.pd = (int)cc[0].predelay;
     C.base = s->base;
+    if (publish) {
+        C.done_flag = e->hd_flag;
+        C.seq = ++e->flag_seq;
+    }
     for (int i = 0; i < 2; i++) {
         C.wet[i] = cc[i].wet;
         C.div[i] = (float)(cc[i].vsteps + 5);
@@ -173,9 +177,21 @@ inline int sf_process(mc_engine* e, const float* in1, const float* in2, float* o
     const size_t cap = (size_t)e->Thost * MC_B;
     std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * nf);
     std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * nf);
-    int rc = sf_call(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, e->hd_io + 2 * cap, e->hd_io + 3 * cap, nf);
+    int rc = sf_call(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, e->hd_io + 2 * cap, e->hd_io + 3 * cap, nf, e->spin_wait);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    if (e->spin_wait) {  // the last workgroup publishes the sequence number once the period is in h_io
+        const unsigned seq = e->flag_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != seq)
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(300)) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (__atomic_load_n(e->h_flag, __ATOMIC_ACQUIRE) != seq) return fail(MC_ERR_HIP, "period did not complete");
+            }
+    } else {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * nf);
     std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * nf);
     return MC_OK;
