@@ -921,7 +921,10 @@ def main():
             "config": {"workload": workload + f", {T} blocks per step, "
                                    + ("IR spectra re-read for every block (streaming MAC)" if a.mode == "stream" else
                                       "sum over partitions by " + str(roofline.get("kernel"))),
-                       "blocks_per_step": T, "partitions": P, "paths": 4 * npairs, "mode": a.mode, "parallelism": "single GPU"},
+                       "blocks_per_step": T, "partitions": P, "paths": 4 * npairs, "mode": a.mode, "parallelism": "single GPU",
+                       **({"note": "fp16 storage exists for the literal streaming MAC only (an HBM stress, BASELINE config 5); the engine's "
+                                   "fast path for this configuration is fp32 with the second-level transform (profiles/r2_bench_cfg5_fp32.json), "
+                                   "two orders of magnitude faster"} if a.precision == "fp16" else {})},
             "roofline": roofline,
             "parity": r.get("parity"),
             "cpu_baseline": r.get("cpu_baseline"),
