@@ -1297,7 +1297,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
             // they read nothing but the block sums k_fwd left and are needed first by k_post)
             CorrArgs ca;
             std::memset(&ca, 0, sizeof(ca));
-            const bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && e->corr_ride;
+            // (every riding workgroup looks at the totals of all chunks before it: beyond ~40 000 blocks - the global batch of
+            // a block-sliced rank - the two launches of run_back are cheaper than that quadratic chain)
+            const bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && T <= 160 * CORR_CHUNK && e->corr_ride;
             auto corr_args = [&]() {
                 ca.sums = d_sums;
                 ca.ptab = d_ptab;

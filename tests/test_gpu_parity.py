@@ -1858,3 +1858,42 @@ def test_output_finished_by_the_inverse_transforms(oracle_mod, gpu_lib, monkeypa
     want[:, nchg * 256:] = u.process(x[0, nchg * 256:nchk * 256], x[1, nchg * 256:nchk * 256])
     err = rms(outs[0][:, :nchk * 256] - want)
     assert err <= RMS_TOL, f"rms {err:.3e}"
+
+
+def test_batch_longer_than_the_riding_prefix_chain(oracle_mod, gpu_lib, monkeypatch):
+    """Batches of more than 160 x 256 blocks: the Q1/Q2 prefix sums do not ride along with the MAC launch (every riding
+    workgroup would look at the totals of all chunks before it) but run as their own two launches ahead of the inverse
+    transforms that finish the output.  Same bits as the k_post route, the oracle's samples at the batch end."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    dev = torch.device("cuda:0")
+    n_ref, T = 8192, 41216
+    irs = [make_ir(6000, seed=3, norm=0.1), make_ir(5000, seed=4, norm=0.1)]
+    x = make_input(T * 256, seed=8)
+    x[0] += 0.04
+    p0, p1 = dict(BASE, predelay=128, wet=0.7), dict(BASE, select=1, panWet=0.4)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MCCONV_FUSE_OUT", fuse)
+        c = _conv(fftSize=n_ref, max_batch=T)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        d_in = torch.from_numpy(x).to(dev)
+        d_out = torch.full((2, T * 256), float("nan"), device=dev)
+        c.process_device(d_in[0].data_ptr(), d_in[1].data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), T)
+        c.sync()
+        outs.append(d_out.cpu().numpy())
+        c.close()
+    assert np.isfinite(outs[0]).all()
+    assert rms(outs[0] - outs[1]) <= 1e-7
+    u = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+    apply_params(u, p0, p1, True)
+    n = 96
+    want = u.range(x[0], x[1], T - n, n)
+    err = rms(outs[0][:, (T - n) * 256:] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e}"
