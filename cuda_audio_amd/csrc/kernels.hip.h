@@ -833,7 +833,17 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     static_assert(sizeof(float2) * IW_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (IW_WAVES + 1), "tile fits the transform buffers");
     float4(*s_tile)[IW_WAVES + 1] = reinterpret_cast<float4(*)[IW_WAVES + 1]>(s_mem);
     load_twiddles(s_tw, g_tw);
-    const int tb0 = blockIdx.x * IW_NEW;
+    // Workgroup ids 8 apart run on one XCD: give each XCD a contiguous run of tiles, so that the 128-byte lines two
+    // neighbouring tiles share (a tile's rows start 16 bytes before a multiple of 15 blocks) are fetched into ONE L2
+    int tile;
+    {
+        const int nt = (int)gridDim.x, q = nt >> 3, r = nt & 7, x = (int)blockIdx.x & 7;
+        tile = x * q + min(x, r) + ((int)blockIdx.x >> 3);
+#ifdef IW_LINEAR_TILES  // (measurement build: tiles in workgroup order)
+        tile = (int)blockIdx.x;
+#endif
+    }
+    const int tb0 = tile * IW_NEW;
     {
         const int c = threadIdx.x % IW_WAVES, k0 = threadIdx.x / IW_WAVES;  // column c <-> block tb0 - 1 + c
         const int t = tb0 - 1 + c;
