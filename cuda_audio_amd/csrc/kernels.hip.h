@@ -786,9 +786,10 @@ struct OutArgs {
     int64_t tabs0;  // first block of the batch (absolute)
     int64_t predelay, n_ref, b0;  // b0: first block of the live predelay epoch
     int compat, pm;
-    int T;                   // blocks in the batch
+    int out_end;             // output frames of batch blocks [out_from, out_end) are emitted; the out buffers start at block out_blk0
+    int out_blk0;            // (whole batch: out_end = T, out_blk0 = 0; a block-sliced engine: its slice)
     int blk0;                // block of the batch this launch starts at
-    int out_from;            // output blocks < out_from are left to k_post (they need wet samples of earlier calls)
+    int out_from;            // whole batch: blocks < out_from are left to k_post (they need wet samples of earlier calls)
     int wet_head, wet_from;  // blocks of the batch < wet_head or >= wet_from also go to the wet ring
 };
 
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         // OUT: the lane's four wet frames [i0, i0 + 4) of the batch sound at output frames [o0, o0 + 4)
         const int64_t i0 = OUT ? ((int64_t)(oa.blk0 + t) * MC_B + m0) : 0;
         const int64_t o0 = i0 + (OUT ? oa.predelay : 0);
-        const bool emits = OUT && o0 + 3 >= (int64_t)oa.out_from * MC_B && o0 < (int64_t)oa.T * MC_B;
+        const bool emits = OUT && o0 + 3 >= (int64_t)oa.out_from * MC_B && o0 < (int64_t)oa.out_end * MC_B;
         const bool whole = emits && ((o0 | oa.n_ref) & 3) == 0 && o0 >= (int64_t)oa.out_from * MC_B;  // one aligned quad (then o0 + 3 is inside too)
         float4 x1q = make_float4(0.f, 0.f, 0.f, 0.f), x2q = x1q;
         if (whole) {
@@ -942,21 +943,22 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 out_frame(true, wl4.y, wr4.y, x1q.y, x2q.y, bp, win, fl.y, fr.y);
                 out_frame(false, wl4.z, wr4.z, x1q.z, x2q.z, bp, win, fl.z, fr.z);
                 out_frame(true, wl4.w, wr4.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
-                *reinterpret_cast<float4*>(oa.outL + o0) = fl;
-                *reinterpret_cast<float4*>(oa.outR + o0) = fr;
+                const int64_t os = o0 - (int64_t)oa.out_blk0 * MC_B;
+                *reinterpret_cast<float4*>(oa.outL + os) = fl;
+                *reinterpret_cast<float4*>(oa.outR + os) = fr;
             } else {
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {  // a predelay that is no multiple of four frames: frame by frame (rolled: registers)
                     const int64_t o = o0 + k;
-                    if (o < (int64_t)oa.out_from * MC_B || o >= (int64_t)oa.T * MC_B) continue;
+                    if (o < (int64_t)oa.out_from * MC_B || o >= (int64_t)oa.out_end * MC_B) continue;
                     const BlockParams& bp = oa.ptab[(o >> 8) * oa.pstride];
                     const float a = k == 0 ? wl4.x : (k == 1 ? wl4.y : (k == 2 ? wl4.z : wl4.w));
                     const float b = k == 0 ? wr4.x : (k == 1 ? wr4.y : (k == 2 ? wr4.z : wr4.w));
                     float fl, fr;
                     out_window(oa, u0 + k, win);
                     out_frame((k & 1) != 0, a, b, oa.in1[o], oa.in2[o], bp, win, fl, fr);
-                    oa.outL[o] = fl;
-                    oa.outR[o] = fr;
+                    oa.outL[o - (int64_t)oa.out_blk0 * MC_B] = fl;
+                    oa.outR[o - (int64_t)oa.out_blk0 * MC_B] = fr;
                 }
             }
         }

@@ -1348,7 +1348,11 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 // final prefix sums go into it: a whole batch on one engine, no Q8 pass, no retired epoch ringing out.
                 OutArgs oa;
                 std::memset(&oa, 0, sizeof(oa));
-                bool fuse = h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !slice && !piped && off == 0 && n == T &&
+                // whole batch: the launch covers it all.  Block-sliced: the launch covers the slice and the reach-back blocks
+                // before it, from which the slice's first predelay frames come - unless the stream starts inside the reach-back
+                const int halo_full = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
+                const bool covers = slice ? (n == halo + count && off == 0 && halo == halo_full) : (off == 0 && n == T);
+                bool fuse = h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !piped && covers &&
                             e->res_end <= e->t_front * MC_B && !make_taildrop(e, st.ctx.vir, st.ctx.predelay).on;
                 if (fuse) {
                     if (!mo.corr_done) {  // the prefix sums as launches of their own, ahead of their reader
@@ -1360,7 +1364,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                                                (int64_t)st.ctx.t0, e->d_ctot);
                         mo.corr_done = true;
                     }
-                    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
+                    const int head = slice ? 0 : (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
                     oa.in1 = d_in1;
                     oa.in2 = d_in2;
                     oa.outL = d_outL;
@@ -1375,10 +1379,19 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                     oa.b0 = make_retired(e).b0;
                     oa.compat = (int)e->cfg.compat;
                     oa.pm = e->pm;
-                    oa.T = T;
-                    oa.out_from = head;
-                    oa.wet_head = head;
-                    oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));  // what later calls and a predelay change can reach
+                    if (slice) {  // the slice [first, first + count), nothing else; a sliced engine keeps no wet history
+                        oa.out_from = first;
+                        oa.out_end = first + count;
+                        oa.out_blk0 = first;
+                        oa.wet_head = 0;
+                        oa.wet_from = 1 << 30;
+                    } else {
+                        oa.out_from = head;
+                        oa.out_end = T;
+                        oa.out_blk0 = 0;
+                        oa.wet_head = head;
+                        oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));  // what later calls and a predelay change can reach
+                    }
                     stored.out_from = head;
                 }
                 launch_inv(e, mo, b, inv_stream, to_wet, fuse ? &oa : nullptr);
@@ -2588,7 +2601,7 @@ int mc_process_batch_slice_device(mc_engine* e, const float* d_in1, const float*
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
     if (e->sf) return fail(MC_ERR_ARG, "the single-transform form has no block slices");
     if (first > (uint64_t)T || count > (uint64_t)T) return fail(MC_ERR_ARG, "slice outside the batch");
-    int rc = run_front(e, d_in1, d_in2, T, nullptr, (int)first, (int)count);
+    int rc = run_front(e, d_in1, d_in2, T, nullptr, (int)first, (int)count, d_outL, d_outR);
     if (rc) return rc;
     return run_back(e, d_in1, d_in2, nullptr, d_outL, d_outR, T);
 }
