@@ -1086,6 +1086,10 @@ struct CorrArgs {
     double* ctot;
     int need_a0, need_a1, need_b0;
     int nchunks;  // 0: nothing rides along
+    // chunk cb covers blocks run0 + 256 cb (cb < nrun0) or run1 + 256 (cb - nrun0): a block-sliced rank transforms only the two
+    // runs of blocks its windows reach, all other terms are zero and their ring entries are never read, so only the chunks
+    // that overlap the runs exist (corr_chunks on the host; a whole batch: run0 = 0, nrun0 = all chunks)
+    int run0, nrun0, run1;
     // chain != 0 (workgroups riding along with another kernel's launch): one pass - a workgroup takes a ticket (its chunk),
     // scans its chunk, publishes the chunk total under flags[chunk] = seq and adds the totals of the chunks before it
     // itself, so the ring is final when the launch ends and k_corr_fix is not needed.  A workgroup waits only for
@@ -1101,7 +1105,7 @@ struct CorrArgs {
 // >= CORR_CHUNK: threads beyond it only keep the barriers company.
 __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], const CorrArgs& A) {
     // blocks outside [need_a0, need_a1) and [need_b0, T) were not transformed (block-sliced rank): zero terms
-    // T <= CORR_CHUNK (one workgroup): the base of the previous batch is added here and k_corr_fix is not run
+    // a single chunk: the base of the previous batch is added here and k_corr_fix is not run
     const int tid = threadIdx.x;
     const bool on = tid < CORR_CHUNK;
     if (A.chain) {  // the chunk is the ticket: tickets are taken in the order the workgroups start
@@ -1111,11 +1115,11 @@ __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], con
         cb = (int)s_ticket;
         if (cb < 0 || cb >= A.nchunks) return;  // (cannot happen: one ticket per riding workgroup)
     }
-    const int t = cb * CORR_CHUNK + tid;
+    const int t = (cb < A.nrun0 ? A.run0 + cb * CORR_CHUNK : A.run1 + (cb - A.nrun0) * CORR_CHUNK) + tid;
     double d[4] = {0, 0, 0, 0};
     if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0))
         corr_terms(A.sums[t], A.ptab[(int64_t)t * A.pstride], A.vs, A.inv_n, d);
-    if (!A.chain && A.T <= CORR_CHUNK && tid == 0 && A.tabs0 > 0) {
+    if (!A.chain && A.nchunks == 1 && tid == 0 && A.tabs0 > 0) {
         const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) d[c] += p[c];
     }
@@ -1184,16 +1188,15 @@ __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], con
 }
 
 // chunk cb: add the totals of the chunks before it (and the previous batch's last prefix entry) to its entries
-__device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], int T, double* __restrict__ cring, int rc, int64_t tabs0,
-                                              const double* __restrict__ ctot) {
+__device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], const CorrArgs& A) {
     const int tid = threadIdx.x;
     const bool on = tid < CORR_CHUNK;
-    const int t = cb * CORR_CHUNK + tid;
+    const int t = (cb < A.nrun0 ? A.run0 + cb * CORR_CHUNK : A.run1 + (cb - A.nrun0) * CORR_CHUNK) + tid;
     // totals of the chunks before this one: strided partial sums, then a tree in LDS (long batches have hundreds)
     double part[4] = {0, 0, 0, 0};
     if (on)
         for (int k = tid; k < cb; k += CORR_CHUNK)
-            for (int c = 0; c < 4; c++) part[c] += ctot[k * 4 + c];
+            for (int c = 0; c < 4; c++) part[c] += A.ctot[k * 4 + c];
     if (on)
         for (int c = 0; c < 4; c++) s_red[tid][c] = part[c];
     __syncthreads();
@@ -1204,12 +1207,12 @@ __device__ __forceinline__ void corr_fix_body(const int cb, double (*s_red)[4], 
     }
     double base[4];
     for (int c = 0; c < 4; c++) base[c] = s_red[0][c];
-    if (tabs0 > 0) {
-        const double* p = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
+    if (A.tabs0 > 0) {
+        const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) base[c] += p[c];
     }
-    if (on && t < T) {
-        double* o = cring + (size_t)((tabs0 + t) & (rc - 1)) * 4;
+    if (on && t < A.T) {
+        double* o = A.cring + (size_t)((A.tabs0 + t) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) o[c] += base[c];
     }
 }
@@ -1219,10 +1222,9 @@ __global__ __launch_bounds__(CORR_CHUNK) void k_corr_terms(CorrArgs A) {
     corr_terms_body((int)blockIdx.x, s_part, A);
 }
 
-__global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(int T, double* __restrict__ cring, int rc, int64_t tabs0,
-                                                         const double* __restrict__ ctot) {
+__global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(CorrArgs A) {
     __shared__ double s_red[CORR_CHUNK][4];
-    corr_fix_body((int)blockIdx.x, s_red, T, cring, rc, tabs0, ctot);
+    corr_fix_body((int)blockIdx.x, s_red, A);
 }
 
 // ---------------------------------------------------------------------------

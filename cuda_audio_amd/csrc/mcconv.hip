@@ -1167,6 +1167,20 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
     return MC_OK;
 }
 
+// The chunks of 256 blocks the Q1/Q2 prefix sums exist for (CorrArgs): the runs [need_a0, need_a1) and [need_b0, T) of a
+// block-sliced rank, everything for a whole batch.  The last block of the batch is always covered (the next call's base).
+void corr_chunks(CorrArgs* ca, int T, int need_a0, int need_a1, int need_b0) {
+    ca->need_a0 = need_a0;
+    ca->need_a1 = need_a1;
+    ca->need_b0 = need_b0;
+    ca->run0 = need_a0 & ~(CORR_CHUNK - 1);
+    ca->nrun0 = need_a1 > ca->run0 ? (std::min(need_a1, T) - ca->run0 + CORR_CHUNK - 1) / CORR_CHUNK : 0;
+    const int end0 = ca->run0 + ca->nrun0 * CORR_CHUNK;
+    ca->run1 = std::max(std::min(need_b0, T - 1) & ~(CORR_CHUNK - 1), end0);
+    const int nrun1 = T > ca->run1 ? (T - ca->run1 + CORR_CHUNK - 1) / CORR_CHUNK : 0;
+    ca->nchunks = ca->nrun0 + nrun1;
+}
+
 // forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial.
 // first/count: the output blocks of the batch this engine will finish (block-sliced operation when count < T):
 // everything that later calls depend on (delay line, gains, Q1/Q2 sums, histories) is still produced for all T
@@ -1297,9 +1311,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
             // they read nothing but the block sums k_fwd left and are needed first by k_post)
             CorrArgs ca;
             std::memset(&ca, 0, sizeof(ca));
-            // (every riding workgroup looks at the totals of all chunks before it: beyond ~40 000 blocks - the global batch of
-            // a block-sliced rank - the two launches of run_back are cheaper than that quadratic chain)
-            const bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && T <= 160 * CORR_CHUNK && e->corr_ride;
+            // (every riding workgroup looks at the totals of all chunks before it: beyond 160 chunks the two launches of
+            // run_back are cheaper than that quadratic chain.  A block-sliced rank has few: only the runs it transforms)
+            bool may_ride = h == 1 && !lin && !piped && to_wet && T > CORR_CHUNK && e->corr_ride;
             auto corr_args = [&]() {
                 ca.sums = d_sums;
                 ca.ptab = d_ptab;
@@ -1312,13 +1326,13 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 ca.rc = e->rc;
                 ca.tabs0 = (int64_t)st.ctx.t0;
                 ca.ctot = e->d_ctot;
-                ca.need_a0 = need_a0;
-                ca.need_a1 = need_a1;
-                ca.need_b0 = need_b0;
-                ca.nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
+                corr_chunks(&ca, T, need_a0, need_a1, need_b0);
             };
             if (may_ride) {
                 corr_args();
+                may_ride = ca.nchunks > 1 && ca.nchunks <= 160;
+            }
+            if (may_ride) {
                 ca.chain = 1;
                 ca.ticket = e->d_cticket;
                 ca.ticket_base = e->cticket_base;
@@ -1359,9 +1373,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                         corr_args();
                         ca.chain = 0;
                         hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, ca);
-                        if (ca.nchunks > 1)
-                            hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, T, e->d_cring, e->rc,
-                                               (int64_t)st.ctx.t0, e->d_ctot);
+                        if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, ca);
                         mo.corr_done = true;
                     }
                     const int head = slice ? 0 : (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
@@ -1428,7 +1440,6 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const BlockParams* d_ptab = e->d_ptab + (size_t)ctx.slot * e->Tmax;
         const float4* d_sums = e->d_sums + (size_t)ctx.slot * e->Tmax;
         // Q1/Q2 prefix sums of this batch (only where the output is finished: a non-root shard skips them)
-        const int nchunks = (T + CORR_CHUNK - 1) / CORR_CHUNK;
         if (!ctx.corr_done) {  // (on the headline path they rode along with the front half's launches)
             CorrArgs ca;
             std::memset(&ca, 0, sizeof(ca));
@@ -1443,14 +1454,9 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             ca.rc = e->rc;
             ca.tabs0 = (int64_t)ctx.t0;
             ca.ctot = e->d_ctot;
-            ca.need_a0 = ctx.need_a0;
-            ca.need_a1 = ctx.need_a1;
-            ca.need_b0 = ctx.need_b0;
-            ca.nchunks = nchunks;
-            hipLaunchKernelGGL(k_corr_terms, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
-            if (nchunks > 1)  // a single chunk adds its base itself
-                hipLaunchKernelGGL(k_corr_fix, dim3(nchunks), dim3(CORR_CHUNK), 0, e->stream, T, e->d_cring, e->rc, (int64_t)ctx.t0,
-                                   e->d_ctot);
+            corr_chunks(&ca, T, ctx.need_a0, ctx.need_a1, ctx.need_b0);
+            hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
+            if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);  // a single chunk adds its base itself
         }
         const bool piped = e->pipelined && !lin_sum && !publish;
         hipStream_t ps = e->stream;
