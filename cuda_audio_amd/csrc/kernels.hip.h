@@ -779,6 +779,8 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
 struct OutArgs {
     const float *in1, *in2;  // the batch's input [T * 256] each
     float *outL, *outR;      // the batch's output
+    float* lin;              // != null (a partition shard): the delayed wet partial [2][out_end * 256] is emitted instead - the
+                             // summand of the cross-GPU reduce, what k_ola produces; no window sums, clamp or dry mix
     const BlockParams* ptab;
     int pstride;
     const double* cring;
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const bool emits = OUT && o0 + 3 >= (int64_t)oa.out_from * MC_B && o0 < (int64_t)oa.out_end * MC_B;
         const bool whole = emits && ((o0 | oa.n_ref) & 3) == 0 && o0 >= (int64_t)oa.out_from * MC_B;  // one aligned quad (then o0 + 3 is inside too)
         float4 x1q = make_float4(0.f, 0.f, 0.f, 0.f), x2q = x1q;
-        if (whole) {
+        if (whole && !oa.lin) {
             x1q = *reinterpret_cast<const float4*>(oa.in1 + o0);
             x2q = *reinterpret_cast<const float4*>(oa.in2 + o0);
         }
@@ -931,7 +933,19 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             *reinterpret_cast<float4*>(wet + at) = wl4;
             *reinterpret_cast<float4*>(wet + wr + at) = wr4;
         }
-        if (emits) {
+        if (emits && oa.lin) {
+            float* pl = oa.lin + o0;
+            float* pr = oa.lin + (size_t)oa.out_end * MC_B + o0;
+            if (whole) {
+                *reinterpret_cast<float4*>(pl) = wl4;
+                *reinterpret_cast<float4*>(pr) = wr4;
+            } else {
+                const float a[4] = {wl4.x, wl4.y, wl4.z, wl4.w}, b[4] = {wr4.x, wr4.y, wr4.z, wr4.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (o0 + k >= (int64_t)oa.out_from * MC_B && o0 + k < (int64_t)oa.out_end * MC_B) pl[k] = a[k], pr[k] = b[k];
+            }
+        } else if (emits) {
             const int64_t u0 = oa.tabs0 * MC_B + i0;
             double win[4];
             if (whole) {
@@ -1037,6 +1051,18 @@ __global__ __launch_bounds__(256) void k_ola(const float* __restrict__ seg, int 
         w.x += r.x;
         w.y += r.y;
     }
+    lin[(size_t)t * MC_B + m] = w.x;
+    lin[(size_t)T * MC_B + (size_t)t * MC_B + m] = w.y;
+}
+
+// the first blocks of a shard's partial when k_inv_wet<true> emitted the rest: their delayed wet frames come from the wet
+// ring (the previous call's tail, and this batch's first blocks, which the fused launch also wrote there).  grid = blocks.
+__global__ __launch_bounds__(256) void k_ola_head(const float* __restrict__ wet, int wr, int T, int64_t tabs0, int64_t predelay,
+                                                  float* __restrict__ lin) {
+    const int t = blockIdx.x, m = threadIdx.x;
+    const int64_t u = (tabs0 + t) * MC_B + m - predelay;
+    float2 w = make_float2(0.f, 0.f);
+    if (u >= 0) w = make_float2(wet[(size_t)(u & (wr - 1))], wet[(size_t)wr + (u & (wr - 1))]);
     lin[(size_t)t * MC_B + m] = w.x;
     lin[(size_t)T * MC_B + (size_t)t * MC_B + m] = w.y;
 }

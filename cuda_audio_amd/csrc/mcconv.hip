@@ -1257,7 +1257,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     st.ctx.win0 = wblock * MC_B;
     // the finished output comes from this engine alone: overlap-add in the inverse-transform kernel, straight into the
     // wet ring (a partition shard's partial goes through k_ola and the segment ring instead)
-    const bool to_wet = !lin && e->inv_to_wet;
+    // ... unless the inverse transforms can emit the delayed partial themselves: no retired epoch ringing out)
+    const bool lin_fused = lin && e->inv_to_wet && e->fuse_out && e->res_end <= e->t_front * MC_B;
+    const bool to_wet = (!lin && e->inv_to_wet) || lin_fused;
     st.ctx.wet_ready = to_wet;
     e->pipe[(e->pipe_head + e->pipe_count) % kPipe] = st.ctx;
     e->spec_valid = false;
@@ -1286,6 +1288,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
         int rc = drain_kernel_events(e);
         if (rc) return rc;
     }
+    int lin_head = 0;  // blocks of a shard's partial that k_ola_head fills (fused form)
     {
         // a window that starts before this batch sees the previous batch's gains too
         bool per_slot = pstride != 0;
@@ -1366,10 +1369,10 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 // before it, from which the slice's first predelay frames come - unless the stream starts inside the reach-back
                 const int halo_full = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
                 const bool covers = slice ? (n == halo + count && off == 0 && halo == halo_full) : (off == 0 && n == T);
-                bool fuse = h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !piped && covers &&
-                            e->res_end <= e->t_front * MC_B && !make_taildrop(e, st.ctx.vir, st.ctx.predelay).on;
+                bool fuse = lin_fused || (h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !piped && covers &&
+                                          e->res_end <= e->t_front * MC_B && !make_taildrop(e, st.ctx.vir, st.ctx.predelay).on);
                 if (fuse) {
-                    if (!mo.corr_done) {  // the prefix sums as launches of their own, ahead of their reader
+                    if (!mo.corr_done && !lin) {  // the prefix sums as launches of their own, ahead of their reader
                         corr_args();
                         ca.chain = 0;
                         hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, inv_stream, ca);
@@ -1381,6 +1384,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                     oa.in2 = d_in2;
                     oa.outL = d_outL;
                     oa.outR = d_outR;
+                    oa.lin = lin;
                     oa.ptab = d_ptab;
                     oa.pstride = pstride;
                     oa.cring = e->d_cring;
@@ -1404,7 +1408,8 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                         oa.wet_head = head;
                         oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));  // what later calls and a predelay change can reach
                     }
-                    stored.out_from = head;
+                    if (!lin) stored.out_from = head;
+                    lin_head = head;
                 }
                 launch_inv(e, mo, b, inv_stream, to_wet, fuse ? &oa : nullptr);
                 if (mo.corr_done) stored.corr_done = true;
@@ -1416,7 +1421,11 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
             }
         }
     }
-    if (lin)
+    if (lin && lin_fused) {
+        if (lin_head > 0)  // the frames the predelay fills from the previous call
+            hipLaunchKernelGGL(k_ola_head, dim3(lin_head), dim3(256), 0, e->stream, e->d_wet, e->wr, T, (int64_t)e->t_front,
+                               (int64_t)st.ctx.predelay, lin);
+    } else if (lin)
         hipLaunchKernelGGL(k_ola, dim3(T), dim3(256), 0, e->stream, e->d_seg, e->sr, T, e->d_wet, e->wr, (int64_t)e->t_front,
                            (int64_t)st.ctx.predelay, make_retired(e), lin);
     HIP_TRY(hipGetLastError());
