@@ -22,7 +22,7 @@
 //     non-zero terms, folded into the input), each on one wavefront (fft512_wave);
 //   * spectra are kept for bins 0 .. N/2 - 1 only; the mirrored half of the reference's buffers is implied.
 // The inverse is the plain four-step: 512-point transforms over c (k_sf_inv1), twiddle, M-point transforms over d in
-// LDS (radix-2 Stockham, k_sf_inv2), whose epilogue accumulates, clamps and - last workgroup out - emits the period.
+// LDS (radix-2 Stockham, k_sf_inv2) or on a wavefront (k_sf_inv2w), whose epilogue accumulates, clamps and emits the period.
 // IR preparation (Convolution::prepare, conv.cu:207-253) is the same four-step forward on the packed L + jR taps
 // (k_sf_ir_cols, k_sf_ir_rows) and the split (k_sf_ir_unpack).
 //
@@ -189,10 +189,11 @@ __device__ __forceinline__ float2* sf_fft_lds(float2* src, float2* dst, const fl
 // y[n = a + 512 b] = {y_L, y_R}; acc[slot(n + pd)] = clamp(acc + y) for
 // n + pd < N.  The accumulators are kept in the order this pass produces:
 // slot t = (base + s) mod N lives at [t mod 512][t / 512], so the M results of
-// one a are one (rotated) contiguous row.  The last workgroup to finish emits the
-// period: out = acc[slot(s)] + dry mix for s < nframes, and clears those slots
-// (they become the far end of the accumulator: the reference shifts zeros in,
-// conv.cu:440-451).
+// one a are one (rotated) contiguous row.  A frame of this period (s < nframes)
+// leaves the moment its one contribution of this call has been added: out = acc +
+// dry mix, and its slot is cleared (it becomes the far end of the accumulator: the
+// reference shifts zeros in, conv.cu:440-451); frames before the predelay get no
+// contribution and leave as they are (sf_emit_early).
 //   k_sf_inv2w (M <= 512): one wavefront per a - the row zero-padded to 512 points,
 //                          U[j] = X[j 512 / M]; grid = 512 / SF_ROWS2, block = 64 SF_ROWS2
 //   k_sf_inv2  (any M)   : AT rows per workgroup, radix-2 Stockham in LDS;
@@ -200,42 +201,52 @@ __device__ __forceinline__ float2* sf_fft_lds(float2* src, float2* dst, const fl
 // ---------------------------------------------------------------------------
 #define SF_ROWS2 4
 
-__device__ __forceinline__ void sf_accumulate(const SfCall& C, int N, int M, int a, int b, float2 v, float* __restrict__ acc) {
-    if ((unsigned)C.pd + (unsigned)a + (unsigned)FFT_N * (unsigned)b >= (unsigned)N) return;  // pushed past the end: dropped (Q8)
-    const unsigned t = C.base + (unsigned)C.pd + (unsigned)a;
-    const size_t at = (size_t)(t & (FFT_N - 1)) * M + (((t >> 9) + (unsigned)b) & (unsigned)(M - 1));
-    acc[at] = fminf(fmaxf(acc[at] + v.x, -1.f), 1.f);
-    acc[(size_t)N + at] = fminf(fmaxf(acc[(size_t)N + at] + v.y, -1.f), 1.f);
+__device__ __forceinline__ size_t sf_slot(const SfCall& C, int M, unsigned s) {  // accumulator entry of output frame s of this call
+    const unsigned t = C.base + s;
+    return (size_t)(t & (FFT_N - 1)) * M + ((t >> 9) & (unsigned)(M - 1));
 }
 
-// every thread of the workgroup calls this after its last accumulator store
-__device__ __forceinline__ void sf_emit_if_last(const SfCall& C, int N, int M, float* __restrict__ acc, unsigned* __restrict__ done_ctr) {
-    __shared__ unsigned s_last;
-    __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+// out = acc + dry mix for a frame of the period; its slot becomes the far end of the accumulator: the reference shifts zeros in
+__device__ __forceinline__ void sf_emit(const SfCall& C, unsigned s, float l, float r) {
+    const float x1 = C.in1[s], x2 = C.in2[s];
+    C.outL[s] = l + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
+    C.outR[s] = r + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
+}
+
+// y[n = a + 512 b] into the accumulator at frame s = n + predelay; frames of this period leave at once
+__device__ __forceinline__ void sf_accumulate(const SfCall& C, int N, int M, int a, int b, float2 v, float* __restrict__ acc) {
+    const unsigned s = (unsigned)C.pd + (unsigned)a + (unsigned)FFT_N * (unsigned)b;
+    if (s >= (unsigned)N) return;  // pushed past the end: dropped (Q8)
+    const size_t at = sf_slot(C, M, s);
+    float l = fminf(fmaxf(acc[at] + v.x, -1.f), 1.f), r = fminf(fmaxf(acc[(size_t)N + at] + v.y, -1.f), 1.f);
+    if (s < (unsigned)C.nframes) {
+        sf_emit(C, s, l, r);
+        l = r = 0.f;
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int s = threadIdx.x; s < C.nframes; s += blockDim.x) {
-        const unsigned t = C.base + (unsigned)s;
-        const size_t at = (size_t)(t & (FFT_N - 1)) * M + ((t >> 9) & (unsigned)(M - 1));
-        // (other workgroups wrote these slots: read past this CU's vector cache)
-        const float wl = __hip_atomic_load(acc + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float wr = __hip_atomic_load(acc + (size_t)N + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float x1 = C.in1[s], x2 = C.in2[s];
-        C.outL[s] = wl + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
-        C.outR[s] = wr + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
+    acc[at] = l;
+    acc[(size_t)N + at] = r;
+}
+
+// frames of the period that lie before the predelay get no contribution from this call: what the accumulator holds leaves
+// as it is.  Called once for every a < 512 (frame s belongs to a = s mod 512).
+__device__ __forceinline__ void sf_emit_early(const SfCall& C, int N, int M, int a, float* __restrict__ acc) {
+    const unsigned lim = (unsigned)min(C.pd, C.nframes);
+    for (unsigned s = (unsigned)a; s < lim; s += FFT_N) {
+        const size_t at = sf_slot(C, M, s);
+        sf_emit(C, s, acc[at], acc[(size_t)N + at]);
         acc[at] = 0.f;
         acc[(size_t)N + at] = 0.f;
     }
-    if (threadIdx.x == 0) *done_ctr = 0;
-    if (C.done_flag) {
-        __syncthreads();  // the period's stores have been issued and acknowledged
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the output is on the host
+}
+
+// mc_process: the last workgroup to get here publishes the sequence number once the whole period is on the host
+__device__ __forceinline__ void sf_publish_if_last(const SfCall& C, unsigned* __restrict__ done_ctr) {
+    if (!C.done_flag) return;
+    __syncthreads();  // every lane's stores have been issued and acknowledged (vmcnt(0) at the barrier)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this workgroup's frames are on the host
+        if (atomicAdd(done_ctr, 1u) == gridDim.x - 1) {
+            *done_ctr = 0;
             __hip_atomic_store(C.done_flag, C.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -259,7 +270,8 @@ __global__ __launch_bounds__(64 * SF_ROWS2) void k_sf_inv2w(SfCall C, int N, int
     fft512_wave<+1, false>(v, s_fft[wave], s_tw, lane);
     const int R = FFT_N / M;
     for (int b = lane; b < M; b += 64) sf_accumulate(C, N, M, a, b, s_fft[wave][b * R], acc);
-    sf_emit_if_last(C, N, M, acc, done_ctr);
+    if (lane == 0) sf_emit_early(C, N, M, a, acc);
+    sf_publish_if_last(C, done_ctr);
 }
 
 __global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT, const float2* __restrict__ Tm,
@@ -274,7 +286,8 @@ __global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT,
     __syncthreads();
     const float2* y = sf_fft_lds(bufA, bufB, tw, M, AT);
     for (int idx = threadIdx.x; idx < AT * M; idx += 256) sf_accumulate(C, N, M, a0 + idx / M, idx % M, y[idx], acc);
-    sf_emit_if_last(C, N, M, acc, done_ctr);
+    if (threadIdx.x < AT) sf_emit_early(C, N, M, a0 + threadIdx.x, acc);
+    sf_publish_if_last(C, done_ctr);
 }
 
 // ---------------------------------------------------------------------------
