@@ -890,6 +890,17 @@ def main():
             bind = labelled_profile("r2_headline_counters.json", "derived") if fused else None
             if bind:
                 roofline["binding_resource"] = bind
+            # the whole step against the same roof: the other launches of a step are pure streams (forward transforms:
+            # input in, delay-line spectra out; inverse transforms + output stage: partition sums and dry input in, output out)
+            step_ms = dt / a.steps * 1e3
+            other = 256 * T * npairs * ((2 * 4 + 16) + (16 + 2 * 4 + 2 * 4))
+            step_bytes = cb["total"] * npairs * max(1, -(-T // max(blk, 1))) + other
+            roofline["whole_step"] = {"compulsory_bytes": step_bytes, "ms": round(step_ms, 4),
+                                      "achieved": round(step_bytes / (step_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                      "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": "compulsory bytes of all launches of a step (k_fwd: 2 inputs in, 16 B per bin out; the "
+                                              "second-level transform as above; inverse transforms + output: 16 B per bin and the dry "
+                                              "input in, 2 channels out) / wall time per step, launch gaps included"}
             roofline["survey_8d_accounting"] = survey
             roofline["direct_form_equivalent_tflops"] = round(achieved_tf, 2)
             roofline["note"] = ("achieved = COMPULSORY bytes of the launch (every delay-line slot of the window once, the four "
