@@ -412,7 +412,7 @@ def main():
         dt, npre = timed(step, lambda: None, a.steps, a.warmup, a.prewarm_ms)
         calls = a.steps * T
         alg = e.algorithmic_bytes_per_block()
-        traffic = 14 * a.fft_size * 8  # bytes the four kernels of a call move (header of csrc/singlefft.hip.h), cache-resident
+        traffic = 12 * a.fft_size * 8  # bytes the three kernels of a call move (header of csrc/singlefft.hip.h), cache-resident
         res = {"T": T, "dt": dt, "alg": alg, "traffic": traffic}
         e.close()
         # same-run parity: the stream from its cold start against the float64 restatement of onProcess (oracle.RefCompat)
@@ -469,15 +469,15 @@ def main():
                                    f"calls, {a.taps}-tap IRs, one {a.fft_size}-point transform per call, 2x2 path matrix; step = "
                                    f"{T} calls back to back (mc_process_batch_device)",
                        "blocks_per_step": T, "form": "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_sf_fwd + k_sf_mac + k_sf_inv1 + k_sf_inv2 (the four launches of one call)",
+            "roofline": {"bound": "hbm", "kernel": "k_sf_fwdmac + k_sf_inv1 + k_sf_inv2w (the three launches of one call)",
                          "achieved": round(r["traffic"] / per_call / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(r["traffic"] / per_call / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_call": r["traffic"], "us_per_call": round(per_call * 1e6, 2),
                          "survey_algorithmic_bytes_per_call": r["alg"],
-                         "note": "bytes the four kernels of a call move by construction (14 n_ref-long complex arrays: live spectra r+w, "
-                                 "selected IRs, X, packed Y, pass-1 result, accumulators) / the call's share of the step. The working "
-                                 "set (about 10 MiB) stays in the 256 MB last-level cache: this is cache bandwidth priced against the "
-                                 "HBM peak; the calls are launch-bound (four dependent launches of a few microseconds each). Not the "
+                         "note": "bytes the three kernels of a call move by construction (12 n_ref-long complex arrays: live spectra r+w, "
+                                 "selected IRs, packed Y, pass-1 result, accumulators) / the call's share of the step. The working "
+                                 "set (about 9 MiB) stays in the 256 MB last-level cache: this is cache bandwidth priced against the "
+                                 "HBM peak; the calls are latency-bound (three dependent launches of a few microseconds each). Not the "
                                  "headline: the partitioned engine runs the same configuration three orders of magnitude faster "
                                  "(profiles/r2_bench_cfg2.json)."},
         }

@@ -127,9 +127,8 @@ struct JackPre {
 // state of the single-transform form (singlefft.hip.h / singlefft_host.hip.h)
 struct SfState {
     int N = 0, M = 0, AT = 1;
-    float2* d_live = nullptr;  // [half][ch][N/2] live IR spectra (the reference's irFFT, conv.h:72)
-    float2* d_X = nullptr;     // [2][N/2] X1, X2
-    float2* d_W = nullptr;     // [N] packed output spectrum
+    float2* d_live = nullptr;  // [half][ch][N/2] live IR spectra (the reference's irFFT, conv.h:72); bin d + M c at [d][c]
+    float2* d_W = nullptr;     // [M][512] packed output spectrum
     float2* d_T = nullptr;     // [512][M] between the inverse passes; IR preparation: the packed taps, then U
     float2* d_Z = nullptr;     // [N] IR preparation
     float* d_acc = nullptr;    // [ch][N] accumulators (conv.h:74 residual): a ring, `base` = slot of the next output frame
@@ -2759,7 +2758,7 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
 int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off, uint64_t bytes, uint64_t dims[4]) {
     if (!e) return fail(MC_ERR_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
-    if (e->sf) {  // single-transform form: 0 = an IR's spectra [H_L | H_R] (float2, n_ref / 2 bins each), 4 = the accumulators [2][512][n_ref / 512]
+    if (e->sf) {  // single-transform form: 0 = an IR's spectra [H_L | H_R] (float2, n_ref / 2 bins each, bin d + (n_ref / 512) c at [d][c]), 4 = the accumulators [2][512][n_ref / 512]
         if (dims) dims[0] = dims[1] = dims[3] = e->cfg.n_ref, dims[2] = (uint64_t)e->Tmax;
         if (!dst || !bytes) return MC_OK;
         const char* src = nullptr;

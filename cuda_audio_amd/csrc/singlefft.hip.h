@@ -20,15 +20,16 @@
 //   * the input has nframes <= 1024 non-zero samples: with N = 512 M, n = a + 512 b, k = d + M c the forward
 //     transform is M transforms of 512 points of the twiddled input (pruned four-step: the pass over b has one or two
 //     non-zero terms, folded into the input), each on one wavefront (fft512_wave);
-//   * spectra are kept for bins 0 .. N/2 - 1 only; the mirrored half of the reference's buffers is implied.
+//   * spectra are kept for bins 0 .. N/2 - 1 only, in the order the four-step passes touch them ([d][c] for bin d + M c);
+//     the mirrored half of the reference's buffers is implied.
 // The inverse is the plain four-step: 512-point transforms over c (k_sf_inv1), twiddle, M-point transforms over d in
 // LDS (radix-2 Stockham, k_sf_inv2) or on a wavefront (k_sf_inv2w), whose epilogue accumulates, clamps and emits the period.
 // IR preparation (Convolution::prepare, conv.cu:207-253) is the same four-step forward on the packed L + jR taps
 // (k_sf_ir_cols, k_sf_ir_rows) and the split (k_sf_ir_unpack).
 //
 // Bytes per call at N = 131072 (all of it lives in the 256 MB last-level cache): live spectra 2 MiB read + 2 MiB
-// written, selected IRs 2 MiB, X 1 MiB w + r, packed Y 1 MiB w + r, pass-1 result 1 MiB w + r, accumulators 1 MiB r + w
-// = 14 MiB; SURVEY §8(d) counts 3 MiB algorithmic (IR half-spectra + input window).
+// written, selected IRs 2 MiB, packed Y 1 MiB w + r, pass-1 result 1 MiB w + r, accumulators 1 MiB r + w = 12 MiB in three
+// launches; SURVEY §8(d) counts 3 MiB algorithmic (IR half-spectra + input window).
 #pragma once
 
 #define SF_ROWS 8  // 512-point transforms (wavefronts) per workgroup of the row kernels
@@ -54,101 +55,96 @@ __device__ __forceinline__ float2 sf_cis(unsigned ph, int N, float sign) {  // e
 }
 
 // ---------------------------------------------------------------------------
-// S1: X1, X2 for bins s = d + M c < N/2 from the period's nframes samples.
-// One wavefront per d and input: waves 0 .. SF_ROWS/2 - 1 take in1, the others in2.
-// grid = 2 M / SF_ROWS, block = 64 SF_ROWS.
+// Layout.  With N = 512 M a bin k = d + M c is kept at [d][c]: the half spectra
+// (IRs, live spectra; bins below N/2 <=> c < 256) as [M][256], the packed output
+// spectrum W as [M][512].  Row d is what one 512-point transform of the four-step
+// passes produces or consumes, so every kernel below touches whole rows.
+// The mirror of bin (d, c) is (M - d, 511 - c) for d > 0 and (0, 512 - c) for d = 0.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * SF_ROWS) void k_sf_fwd(SfCall C, int N, int M, float2* __restrict__ X,
-                                                         const float2* __restrict__ g_tw) {
-    constexpr int RD = SF_ROWS / 2;  // values of d per workgroup
+// S1 + S2: X1, X2 of the rows d0 .. d0 + 3 from the period's nframes samples (one
+// wavefront per row and input: waves 0 .. 3 take in1, 4 .. 7 in2), then per bin of
+// those rows: the four live spectra take their step towards wet x the selected IR
+// (f_interpolate), the two output spectra are formed (f_pointwiseMultiplyAndScale)
+// and packed for ONE inverse transform, W = Yh_L + j Yh_R with Yh the Hermitian
+// part (Re at bin 0, 0 at N/2) - at the bin and at its mirror.
+// grid = M / 4, block = 512.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * SF_ROWS) void k_sf_fwdmac(SfCall C, int N, int M, float2* __restrict__ live,
+                                                            float2* __restrict__ W, const float2* __restrict__ g_tw) {
+    constexpr int RD = SF_ROWS / 2;  // rows per workgroup
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
     load_twiddles(s_tw, g_tw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = wave / RD, d0 = blockIdx.x * RD, d = d0 + wave % RD;
-    const float* in = i ? C.in2 : C.in1;
-    float2 v[8];
+    const int d0 = blockIdx.x * RD;
+    {
+        const int i = wave / RD, d = d0 + wave % RD;
+        const float* in = i ? C.in2 : C.in1;
+        float2 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        float2 acc = make_float2(0.f, 0.f);
-        for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
-            const float x = in[n];
-            const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
-            acc.x += x * w.x;
-            acc.y += x * w.y;
+        for (int r = 0; r < 8; r++) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
+                const float x = in[n];
+                const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
+                acc.x += x * w.x;
+                acc.y += x * w.y;
+            }
+            v[r] = acc;
         }
-        v[r] = acc;
+        __syncthreads();
+        fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
     }
     __syncthreads();
-    fft512_wave<-1, false>(v, s_fft[wave], s_tw, lane);
-    __syncthreads();
-    // bins d0 + di + M c, c < 256, of both inputs: RD consecutive bins per c
-    for (int idx = threadIdx.x; idx < SF_ROWS * 256; idx += 64 * SF_ROWS) {
-        const int w = idx % SF_ROWS, c = idx / SF_ROWS;
-        const int s = d0 + w % RD + M * c;
-        if (s) X[(size_t)(w / RD) * (N / 2) + s] = s_fft[w][c];
-    }
-    if (d0 == 0 && threadIdx.x == 0) {
-        // the split's s == 0 shortcut (Q1): X1[0] = Z[0] = S1 + j S2, X2[0] = 0; entry 0 of d = 0 is the sum of the samples
-        X[0] = make_float2(s_fft[0][0].x, s_fft[RD][0].x);
-        X[(size_t)(N / 2)] = make_float2(0.f, 0.f);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// S2: per bin s < N/2 - the four live spectra take their step towards wet x the
-// selected IR, the two output spectra are formed and packed for one inverse
-// transform: W = Yh_L + j Yh_R with Yh the Hermitian part (Re at s = 0, 0 at N/2).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sf_mac(SfCall C, int N, const float2* __restrict__ X, float2* __restrict__ live,
-                                                float2* __restrict__ W) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
     const int H = N / 2;
-    if (s >= H) return;
-    const float2 x[2] = {X[s], X[(size_t)H + s]};
-    float2 y[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            float2* lp = live + (size_t)(i * 2 + c) * H + s;
-            const float2 va = *lp, b = C.b[i][(size_t)c * H + s];
-            const float2 vb = make_float2(b.x * C.wet[i], b.y * C.wet[i]);
-            const float2 vv = make_float2(va.x + (vb.x - va.x) / C.div[i], va.y + (vb.y - va.y) / C.div[i]);
-            *lp = vv;
-            const float2 p = make_float2(x[i].x * vv.x - x[i].y * vv.y, x[i].x * vv.y + x[i].y * vv.x);
-            y[c].x += p.x * C.sc[c][i];
-            y[c].y += p.y * C.sc[c][i];
+    for (int idx = threadIdx.x; idx < RD * 256; idx += 64 * SF_ROWS) {
+        const int di = idx >> 8, c = idx & 255, d = d0 + di;
+        float2 x[2] = {s_fft[di][c], s_fft[RD + di][c]};
+        if (d == 0 && c == 0) {  // the split's s == 0 shortcut (Q1): X1[0] = Z[0] = S1 + j S2, X2[0] = 0
+            x[0] = make_float2(x[0].x, x[1].x);
+            x[1] = make_float2(0.f, 0.f);
         }
-    if (s == 0) {
-        W[0] = make_float2(y[0].x, y[1].x);
-        W[H] = make_float2(0.f, 0.f);
-    } else {
-        W[s] = make_float2(y[0].x - y[1].y, y[0].y + y[1].x);       // Y_L + j Y_R
-        W[N - s] = make_float2(y[0].x + y[1].y, -y[0].y + y[1].x);  // conj(Y_L) + j conj(Y_R)
+        const size_t p = (size_t)d * 256 + c;
+        float2 y[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                float2* lp = live + (size_t)(i * 2 + ch) * H + p;
+                const float2 va = *lp, b = C.b[i][(size_t)ch * H + p];
+                const float2 vb = make_float2(b.x * C.wet[i], b.y * C.wet[i]);
+                const float2 vv = make_float2(va.x + (vb.x - va.x) / C.div[i], va.y + (vb.y - va.y) / C.div[i]);
+                *lp = vv;
+                const float2 pr = make_float2(x[i].x * vv.x - x[i].y * vv.y, x[i].x * vv.y + x[i].y * vv.x);
+                y[ch].x += pr.x * C.sc[ch][i];
+                y[ch].y += pr.y * C.sc[ch][i];
+            }
+        if (d == 0 && c == 0) {
+            W[0] = make_float2(y[0].x, y[1].x);
+            W[256] = make_float2(0.f, 0.f);  // bin N/2 = (0, 256)
+        } else {
+            W[(size_t)d * FFT_N + c] = make_float2(y[0].x - y[1].y, y[0].y + y[1].x);  // Y_L + j Y_R
+            const size_t mir = d ? (size_t)(M - d) * FFT_N + (FFT_N - 1 - c) : (size_t)(FFT_N - c);
+            W[mir] = make_float2(y[0].x + y[1].y, -y[0].y + y[1].x);  // conj(Y_L) + j conj(Y_R)
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
-// S3: inverse, pass 1 - for each d: 512 points over c of W[d + M c] -> a,
+// S3: inverse, pass 1 - for each d: 512 points over c of row d of W -> a,
 // times exp(+2 pi i a d / N), to T[a M + d].  grid = M / SF_ROWS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * SF_ROWS) void k_sf_inv1(int N, int M, const float2* __restrict__ W, float2* __restrict__ Tm,
                                                           const float2* __restrict__ g_tw) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[SF_ROWS][FFT_WAVE_LDS];
-    __shared__ float2 s_in[SF_ROWS][FFT_N + 1];
     load_twiddles(s_tw, g_tw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d0 = blockIdx.x * SF_ROWS;
-    for (int idx = threadIdx.x; idx < SF_ROWS * FFT_N; idx += 64 * SF_ROWS) {
-        const int di = idx % SF_ROWS, c = idx / SF_ROWS;
-        s_in[di][c] = W[(size_t)d0 + di + (size_t)M * c];
-    }
-    __syncthreads();
     float2 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = s_in[wave][lane + 64 * r];
+    for (int r = 0; r < 8; r++) v[r] = W[(size_t)(d0 + wave) * FFT_N + lane + 64 * r];
+    __syncthreads();
     fft512_wave<+1, false>(v, s_fft[wave], s_tw, lane);
     __syncthreads();
     for (int idx = threadIdx.x; idx < SF_ROWS * FFT_N; idx += 64 * SF_ROWS) {
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(256) void k_sf_inv2(SfCall C, int N, int M, int AT,
 // transform, then the two-for-one split.
 //   k_sf_ir_cols: for each a: M points over b of z[a + 512 b] -> d, times exp(-2 pi i a d / N), to U[d 512 + a]
 //   k_sf_ir_rows: for each d: 512 points over a of U[d 512 + a] -> c, to Z[d + M c]
-//   k_sf_ir_unpack: H_L[s], H_R[s] for s < N/2 from Z[s], Z[N - s] (s == 0: the shortcut of conv.cu:53; Q1)
+//   k_sf_ir_unpack: H_L, H_R for bins s < N/2 from Z[s], Z[N - s] (s == 0: the shortcut of conv.cu:53; Q1), stored [d][c]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sf_ir_cols(int N, int M, int AT, const float2* __restrict__ z, float2* __restrict__ U) {
     extern __shared__ float2 sf_sm[];
@@ -337,10 +333,11 @@ __global__ __launch_bounds__(64 * SF_ROWS) void k_sf_ir_rows(int M, const float2
     }
 }
 
-__global__ __launch_bounds__(256) void k_sf_ir_unpack(int N, const float2* __restrict__ Z, float2* __restrict__ Hb) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_sf_ir_unpack(int N, int M, const float2* __restrict__ Z, float2* __restrict__ Hb) {
+    const int p = blockIdx.x * 256 + threadIdx.x;  // [d][c], bin s = d + M c
     const int H = N / 2;
-    if (s >= H) return;
+    if (p >= H) return;
+    const int s = (p >> 8) + M * (p & 255);
     const float2 va = Z[s];
     float2 vb = va;
     if (s) {
@@ -349,6 +346,6 @@ __global__ __launch_bounds__(256) void k_sf_ir_unpack(int N, const float2* __res
     }
     const float2 la = make_float2(0.5f * (va.x + vb.x), 0.5f * (va.y + vb.y));
     const float2 dd = make_float2(-0.5f * (va.x - vb.x), -0.5f * (va.y - vb.y));
-    Hb[s] = la;
-    Hb[(size_t)H + s] = make_float2(-dd.y, dd.x);  // times j
+    Hb[p] = la;
+    Hb[(size_t)H + p] = make_float2(-dd.y, dd.x);  // times j
 }

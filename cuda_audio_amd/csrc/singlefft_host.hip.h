@@ -4,7 +4,6 @@ inline void sf_free(mc_engine* e) {
     SfState* s = e->sf;
     if (!s) return;
     (void)hipFree(s->d_live);
-    (void)hipFree(s->d_X);
     (void)hipFree(s->d_W);
     (void)hipFree(s->d_T);
     (void)hipFree(s->d_Z);
@@ -44,7 +43,6 @@ inline int sf_create(mc_engine* e) {
     s->lds_bytes = sizeof(float2) * (size_t)(2 * s->AT * s->M + s->M / 2);
     s->stockham = std::getenv("MCCONV_SF_STOCKHAM") != nullptr;  // (tests: the LDS transform of the long sizes at a short one)
     HIP_TRY(hipMalloc(&s->d_live, sizeof(float2) * 4 * (size_t)(N / 2)));
-    HIP_TRY(hipMalloc(&s->d_X, sizeof(float2) * N));
     HIP_TRY(hipMalloc(&s->d_W, sizeof(float2) * N));
     HIP_TRY(hipMalloc(&s->d_T, sizeof(float2) * N));
     HIP_TRY(hipMalloc(&s->d_Z, sizeof(float2) * N));
@@ -72,11 +70,11 @@ inline int sf_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t fram
         sm[2] += sg * lr[2 * m];
         sm[3] += sg * lr[2 * m + 1];
     }
-    if (!ir.d_S) HIP_TRY(hipMalloc(&ir.d_S, sizeof(float2) * N));  // [H_L | H_R], N/2 bins each
+    if (!ir.d_S) HIP_TRY(hipMalloc(&ir.d_S, sizeof(float2) * N));  // [H_L | H_R], N/2 bins each, bin d + M c at [d][c]
     HIP_TRY(hipMemcpy(s->d_W, z.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_sf_ir_cols, dim3(FFT_N / s->AT), dim3(256), s->lds_bytes, e->stream, s->N, s->M, s->AT, s->d_W, s->d_T);
     hipLaunchKernelGGL(k_sf_ir_rows, dim3(s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, s->M, s->d_T, s->d_Z, e->d_tw);
-    hipLaunchKernelGGL(k_sf_ir_unpack, dim3((s->N / 2 + 255) / 256), dim3(256), 0, e->stream, s->N, s->d_Z, ir.d_S);
+    hipLaunchKernelGGL(k_sf_ir_unpack, dim3((s->N / 2 + 255) / 256), dim3(256), 0, e->stream, s->N, s->M, s->d_Z, ir.d_S);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::memcpy(ir.sums, sm, sizeof(sm));
@@ -125,8 +123,7 @@ inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL
             C.dry[c][i] = (float)((double)cc[i].dry * pdry[c] * (double)cc[i].level);
         }
     }
-    hipLaunchKernelGGL(k_sf_fwd, dim3(2 * s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, C, s->N, s->M, s->d_X, e->d_tw);
-    hipLaunchKernelGGL(k_sf_mac, dim3((s->N / 2 + 255) / 256), dim3(256), 0, e->stream, C, s->N, s->d_X, s->d_live, s->d_W);
+    hipLaunchKernelGGL(k_sf_fwdmac, dim3(2 * s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, C, s->N, s->M, s->d_live, s->d_W, e->d_tw);
     hipLaunchKernelGGL(k_sf_inv1, dim3(s->M / SF_ROWS), dim3(64 * SF_ROWS), 0, e->stream, s->N, s->M, s->d_W, s->d_T, e->d_tw);
     if (s->M <= FFT_N && !s->stockham)
         hipLaunchKernelGGL(k_sf_inv2w, dim3(FFT_N / SF_ROWS2), dim3(64 * SF_ROWS2), 0, e->stream, C, s->N, s->M, s->d_T, s->d_acc, s->d_ctr, e->d_tw);
