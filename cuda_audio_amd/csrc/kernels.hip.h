@@ -1620,8 +1620,8 @@ struct TailArgs {
 };
 
 __device__ __forceinline__ void tail1_body(const TailArgs& A) {
-    const float* __restrict__ in1 = A.in1;
-    const float* __restrict__ in2 = A.in2;
+    const float* in1 = A.in1;
+    const float* in2 = A.in2;
     const VoiceSet& vset = A.vset;
     const int pstride_ir = A.pstride_ir;
     float4* __restrict__ fdl = A.fdl;
@@ -1756,7 +1756,9 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
 #ifdef MC_JACK_TRACE  // diagnostic build: when the period's work started and ended (100 MHz), next to the completion word
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    const float xin1 = in1[tid], xin2 = in2[tid];
+    // (system scope: the period may sit in device memory the CPU wrote through the BAR - not to be served from a cache)
+    const float xin1 = __hip_atomic_load(in1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float xin2 = __hip_atomic_load(in2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     s_in[0][tid] = xin1;
     s_in[1][tid] = xin2;
     __syncthreads();

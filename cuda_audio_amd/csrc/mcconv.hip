@@ -6,6 +6,7 @@
 // and N-long overlap-add accumulator (conv.h:72-75), the per-half parameters
 // (cc[2].value, conv.h:33-50) and the running-mean timer (conv.h:61,79-80).
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -244,6 +245,11 @@ struct mc_engine {
     unsigned long long park_ticks = 10000000ull;  // a parked tail gives up after this many 100 MHz ticks (100 ms; MCCONV_PARK_MS)
     unsigned long long* h_bell = nullptr;         // mapped: {sequence number, command} the parked tail polls
     unsigned long long* hd_bell = nullptr;
+    // JACK path on a large-BAR system: doorbell and period input live in fine-grained DEVICE memory that the CPU writes
+    // straight through the BAR (posted writes), so the parked tail polls and reads locally instead of over PCIe
+    // (MCCONV_BAR_IO=0: mapped host memory as before).  bar[0..7] = the doorbell's line, then in1, in2 (256 floats each).
+    float* d_bar = nullptr;
+    bool bar_io = false;
     unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
     unsigned* hd_exited = nullptr;
 #ifdef MC_JACK_TRACE
@@ -294,7 +300,13 @@ void host_twiddles(std::vector<float2>& tw) {
 }
 
 void ring_bell(mc_engine* e, unsigned seq, unsigned command) {
-    // the period (h_io) was written before: release order makes it visible to the tail that acquires the doorbell
+    // the period was written before: release order makes it visible to the tail that acquires the doorbell
+    if (e->bar_io) {
+        _mm_sfence();  // the period's write-combined stores leave before the doorbell's
+        __atomic_store_n(reinterpret_cast<unsigned long long*>(e->d_bar), ((unsigned long long)command << 32) | seq, __ATOMIC_RELEASE);
+        _mm_sfence();  // ... and the doorbell does not wait in the write-combining buffer
+        return;
+    }
     __atomic_store_n(e->h_bell, ((unsigned long long)command << 32) | seq, __ATOMIC_RELEASE);
 }
 
@@ -1566,8 +1578,13 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     const auto tr0 = std::chrono::steady_clock::now();
 #endif
     const size_t cap = (size_t)e->Thost * MC_B;
-    std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
-    std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
+    if (e->bar_io) {
+        std::memcpy(e->d_bar + 16, in1, sizeof(float) * MC_B);
+        std::memcpy(e->d_bar + 16 + MC_B, in2, sizeof(float) * MC_B);
+    } else {
+        std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
+        std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
+    }
     mc_cc_value cc[2];
     {
         int rc = sample_params(e, cc);
@@ -1656,8 +1673,8 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     auto tail_args = [&](const Staged& st, const Plan& pl, uint64_t blk, unsigned seq, bool parked) {
         TailArgs A;
         std::memset(&A, 0, sizeof(A));
-        A.in1 = e->hd_io + 0 * cap;
-        A.in2 = e->hd_io + 1 * cap;
+        A.in1 = e->bar_io ? e->d_bar + 16 : e->hd_io + 0 * cap;
+        A.in2 = e->bar_io ? e->d_bar + 16 + MC_B : e->hd_io + 1 * cap;
         A.vset = pl.vset;
         A.pstride_ir = e->Pstride;
         A.fdl = e->d_fdl;
@@ -1688,7 +1705,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.done_flag = e->hd_flag;
         A.seq = seq;
         A.ret = make_retired(e);
-        A.bell = parked ? e->hd_bell : nullptr;
+        A.bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
         A.exited = e->hd_exited;
         A.park_ticks = e->park_ticks;
         return A;
@@ -2286,6 +2303,18 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->h_exited = e->h_flag + 32;
     e->hd_exited = e->hd_flag + 32;
     if (std::getenv("MCCONV_NO_PARK")) e->park = false;
+    {
+        int large_bar = 0;
+        const char* bi = std::getenv("MCCONV_BAR_IO");
+        if ((!bi || std::atoi(bi) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags((void**)&e->d_bar, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+            ENG_TRY(hipMemset(e->d_bar, 0, 4096));
+            e->bar_io = true;
+        } else {
+            (void)hipGetLastError();
+            e->d_bar = nullptr;
+        }
+    }
     if (const char* pm = std::getenv("MCCONV_PARK_MS")) e->park_ticks = (unsigned long long)std::max(1, std::atoi(pm)) * 100000ull;
     ENG_TRY(hipMalloc(&e->d_done_ctr, sizeof(unsigned)));
     ENG_TRY(hipMemset(e->d_done_ctr, 0, sizeof(unsigned)));
@@ -2399,6 +2428,7 @@ void mc_destroy(mc_engine* e) {
     }
     if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
     if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
+    if (e->d_bar) (void)hipFree(e->d_bar);
     if (e->h_io) (void)hipHostFree(e->h_io);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     for (int i = 0; i < kStageBufs; i++) {
