@@ -2016,8 +2016,9 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
     float xin[PM][2];
 #pragma unroll
     for (int j = 0; j < PM; j++) {
-        xin[j][0] = in1[j * MC_B + tid];
-        xin[j][1] = in2[j * MC_B + tid];
+        // (system scope: the period may sit in device memory the CPU wrote through the BAR)
+        xin[j][0] = __hip_atomic_load(in1 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        xin[j][1] = __hip_atomic_load(in2 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float2 tw0 = g_tw[tid], tw1 = g_tw[tid + 256];
     float4 ysum[PM];

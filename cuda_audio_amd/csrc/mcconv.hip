@@ -247,7 +247,7 @@ struct mc_engine {
     unsigned long long* hd_bell = nullptr;
     // JACK path on a large-BAR system: doorbell and period input live in fine-grained DEVICE memory that the CPU writes
     // straight through the BAR (posted writes), so the parked tail polls and reads locally instead of over PCIe
-    // (MCCONV_BAR_IO=0: mapped host memory as before).  bar[0..7] = the doorbell's line, then in1, in2 (256 floats each).
+    // (MCCONV_BAR_IO=0: mapped host memory as before).  16 floats = the doorbell's line, then in1, in2 (room for 1024 frames each).
     float* d_bar = nullptr;
     bool bar_io = false;
     unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
@@ -1580,7 +1580,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     const size_t cap = (size_t)e->Thost * MC_B;
     if (e->bar_io) {
         std::memcpy(e->d_bar + 16, in1, sizeof(float) * MC_B);
-        std::memcpy(e->d_bar + 16 + MC_B, in2, sizeof(float) * MC_B);
+        std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, sizeof(float) * MC_B);
     } else {
         std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
         std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
@@ -1674,7 +1674,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         TailArgs A;
         std::memset(&A, 0, sizeof(A));
         A.in1 = e->bar_io ? e->d_bar + 16 : e->hd_io + 0 * cap;
-        A.in2 = e->bar_io ? e->d_bar + 16 + MC_B : e->hd_io + 1 * cap;
+        A.in2 = e->bar_io ? e->d_bar + 16 + 4 * MC_B : e->hd_io + 1 * cap;
         A.vset = pl.vset;
         A.pstride_ir = e->Pstride;
         A.fdl = e->d_fdl;
@@ -2013,8 +2013,17 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     }
     const int pm = e->pm;
     const size_t bytes = (size_t)pm * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
-    std::memcpy(e->h_io + 0 * cap, in1, bytes);
-    std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    const float *pin1 = e->hd_io + 0 * cap, *pin2 = e->hd_io + 1 * cap;
+    if (e->bar_io) {  // the period straight into device memory through the BAR (see mc_engine::d_bar)
+        std::memcpy(e->d_bar + 16, in1, bytes);
+        std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, bytes);
+        _mm_sfence();
+        pin1 = e->d_bar + 16;
+        pin2 = e->d_bar + 16 + 4 * MC_B;
+    } else {
+        std::memcpy(e->h_io + 0 * cap, in1, bytes);
+        std::memcpy(e->h_io + 1 * cap, in2, bytes);
+    }
     Staged st;
     {
         mc_cc_value cc[2];
@@ -2086,7 +2095,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     }
     e->spec_valid = false;
 #define MC_LAUNCH_TAILP(PM)                                                                                                  \
-    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, e->hd_io + 0 * cap, e->hd_io + 1 * cap, vset, e->Pstride, \
+    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, pin1, pin2, vset, e->Pstride, \
                        e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr,  \
                        e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,     \
                        (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,      \
@@ -2307,8 +2316,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         int large_bar = 0;
         const char* bi = std::getenv("MCCONV_BAR_IO");
         if ((!bi || std::atoi(bi) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large_bar &&
-            hipExtMallocWithFlags((void**)&e->d_bar, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
-            ENG_TRY(hipMemset(e->d_bar, 0, 4096));
+            hipExtMallocWithFlags((void**)&e->d_bar, 16384, hipDeviceMallocFinegrained) == hipSuccess) {
+            ENG_TRY(hipMemset(e->d_bar, 0, 16384));
             e->bar_io = true;
         } else {
             (void)hipGetLastError();
