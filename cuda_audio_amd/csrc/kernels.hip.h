@@ -1998,7 +1998,9 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
                                                double inv_n, int compat, int64_t tabs0, int64_t predelay, int64_t n_ref,
                                                float* __restrict__ outL, float* __restrict__ outR,
                                                const float2* __restrict__ g_tw, TailDrop td, uint2* __restrict__ fdl16,
-                                               unsigned* __restrict__ done_flag, unsigned seq, Retired ret) {
+                                               unsigned* __restrict__ done_flag, unsigned seq, Retired ret,
+                                               const unsigned long long* bell, unsigned* exited, unsigned long long park_ticks) {
+    // bell != null: launched one call ahead, parks on its doorbell like the single-block tail (tail1_body)
     static_assert(PM == 2 || PM == 4, "one wave per block of the call");
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[PM][FFT_WAVE_LDS];
@@ -2014,11 +2016,13 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
 
     // ---- loads with addresses known at entry (one round of memory latency; see k_tail1) ----
     float xin[PM][2];
+    if (!bell) {
 #pragma unroll
-    for (int j = 0; j < PM; j++) {
-        // (system scope: the period may sit in device memory the CPU wrote through the BAR)
-        xin[j][0] = __hip_atomic_load(in1 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        xin[j][1] = __hip_atomic_load(in2 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int j = 0; j < PM; j++) {
+            // (system scope: the period may sit in device memory the CPU wrote through the BAR)
+            xin[j][0] = __hip_atomic_load(in1 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            xin[j][1] = __hip_atomic_load(in2 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     const float2 tw0 = g_tw[tid], tw1 = g_tw[tid + 256];
     float4 ysum[PM];
@@ -2062,6 +2066,37 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
     }
     s_tw[tid] = tw0;
     s_tw[tid + 256] = tw1;
+    if (bell) {
+        // Parked: everything above was requested without the period; only its samples are still missing.  One lane polls
+        // the doorbell, the others wait at the barrier.
+        __shared__ int s_go;
+        if (tid == 0) {
+            int go = 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)v == seq) {
+                    go = (v >> 32) == 0;
+                    break;
+                }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > park_ticks) {
+                    go = 0;
+                    __hip_atomic_store(exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) return;  // nothing has been written: the host launches this period again
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the period was written before the doorbell
+#pragma unroll
+        for (int j = 0; j < PM; j++) {
+            xin[j][0] = __hip_atomic_load(in1 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            xin[j][1] = __hip_atomic_load(in2 + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < PM; j++) {
         s_in[0][j * MC_B + tid] = xin[j][0];

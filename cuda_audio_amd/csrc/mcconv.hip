@@ -121,6 +121,7 @@ struct JackPre {
     unsigned seq = 0;     // its doorbell / completion value
     mc_cc_value cc[2];    // the parameters it was staged with
     Staged st;
+    int pm = 1;           // blocks per period it was staged for
     bool carries_sweep = false;  // its kernel also runs the sweep of block + 1 ...
     int carried_vir[2];          // ... for this IR pair
 };
@@ -1720,8 +1721,8 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         return a.select == b.select && a.predelay == b.predelay && a.speed == b.speed && a.vsteps == b.vsteps && a.dry == b.dry &&
                a.wet == b.wet && a.panDry == b.panDry && a.panWet == b.panWet && a.level == b.level;
     };
-    const bool hit = e->pre.valid && e->pre.block == e->t_front && same_cc(cc[0], e->pre.cc[0]) && same_cc(cc[1], e->pre.cc[1]) &&
-                     cc[0].predelay == e->cur_delay;
+    const bool hit = e->pre.valid && e->pre.pm == 1 && e->pre.block == e->t_front && same_cc(cc[0], e->pre.cc[0]) &&
+                     same_cc(cc[1], e->pre.cc[1]) && cc[0].predelay == e->cur_delay;
     if (hit) {
         my_seq = e->pre.seq;
         ring_bell(e, my_seq, 0);
@@ -1814,6 +1815,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                 hipLaunchKernelGGL(k_jack<false>, grid, dim3(256), 0, e->stream, A, S);
             HIP_TRY(hipGetLastError());
             e->pre.valid = true;
+            e->pre.pm = 1;
             e->pre.block = e->t_front;
             e->pre.seq = seq;
             e->pre.cc[0] = cc[0];
@@ -1998,19 +2000,13 @@ int process_period(mc_engine* e, const float* in1, const float* in2, float* outL
 }
 
 // One JACK period of 512 / 1024 frames on an unsharded engine: the streaming MAC over partitions >= pm (summed
-// speculatively in the shadow of the previous period, as in process_one) and the fused k_tailp.
+// speculatively in the shadow of the previous period, as in process_one) and the fused k_tailp.  In the steady state the
+// NEXT period's k_tailp is launched behind its sweep one call ahead and parks on the doorbell (as process_one's tail does):
+// the call that brings the period writes it through the BAR, rings, and waits - no launch on its critical path.
 int process_period_fused(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
     if (!in1 || !in2 || !outL || !outR) return fail(MC_ERR_ARG, "null buffer");
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
-    {
-        int rc = drain_post(e);
-        if (rc) return rc;
-    }
-    {
-        int rc = leave_jack_path(e);
-        if (rc) return rc;
-    }
     const int pm = e->pm;
     const size_t bytes = (size_t)pm * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
     const float *pin1 = e->hd_io + 0 * cap, *pin2 = e->hd_io + 1 * cap;
@@ -2024,38 +2020,38 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         std::memcpy(e->h_io + 0 * cap, in1, bytes);
         std::memcpy(e->h_io + 1 * cap, in2, bytes);
     }
-    Staged st;
+    mc_cc_value cc[2];
     {
-        mc_cc_value cc[2];
         int rc = sample_params(e, cc);
-        if (!rc) rc = retire_epoch(e, cc[0].predelay);
-        if (!rc) rc = stage_params(e, pm, cc, &st);
         if (rc) return rc;
     }
-    if (st.ctx.pstride != 0) return fail(MC_ERR_STATE, "the blocks of one period must share their parameters");
-    const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
 
-    ActiveVoice sweep[MC_MAXV];
-    int hi[MC_MAXV], nsweep = 0;
-    VoiceSet vset;
-    std::memset(&vset, 0, sizeof(vset));
-    for (int a = 0; a < st.nact; a++) {
-        const int pe = st.act[a].p_end;
-        if (pe <= 0) continue;
-        vset.vid[vset.n] = st.act[a].v;
-        vset.H0[vset.n] = st.act[a].ir0->d_H;
-        vset.H1[vset.n] = st.act[a].ir1->d_H;
-        vset.n++;
-        if (pe > pm) {
-            sweep[nsweep] = st.act[a];
-            hi[nsweep] = pe;
-            nsweep++;
+    // ---- what a staged period sweeps and what its tail multiplies itself
+    struct PPlan {
+        ActiveVoice sweep[MC_MAXV];
+        int hi[MC_MAXV], nsweep = 0, nsum = 1;
+        VoiceSet vset;
+    };
+    auto make_pplan = [&](const Staged& st, PPlan& pl) {
+        std::memset(&pl.vset, 0, sizeof(pl.vset));
+        pl.nsweep = 0;
+        for (int a = 0; a < st.nact; a++) {
+            const int pe = st.act[a].p_end;
+            if (pe <= 0) continue;
+            pl.vset.vid[pl.vset.n] = st.act[a].v;
+            pl.vset.H0[pl.vset.n] = st.act[a].ir0->d_H;
+            pl.vset.H1[pl.vset.n] = st.act[a].ir1->d_H;
+            pl.vset.n++;
+            if (pe > pm) {
+                pl.sweep[pl.nsweep] = st.act[a];
+                pl.hi[pl.nsweep] = pe;
+                pl.nsweep++;
+            }
         }
-    }
-    const int nsum = std::max(1, nsweep) * e->nchunk;
-
+        pl.nsum = std::max(1, pl.nsweep) * e->nchunk;
+    };
     // partitions >= pm of the pm blocks starting at `blk` pair only with blocks before blk
-    auto launch_mac = [&](uint64_t blk) -> int {
+    auto launch_mac = [&](const PPlan& pl, uint64_t blk) -> int {
         const bool timed = e->ktiming;
         if (timed) {
             if (e->kev_n == kEvPool) {
@@ -2067,11 +2063,11 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         }
         const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
         int swept = 0;
-        for (int a = 0; a < nsweep; a++) {
-            ActiveVoice av = sweep[a];
-            av.uniform = e->gain_change_block[av.v] + (uint64_t)hi[a] <= blk && e->gain_change_block[av.v] < blk;
-            launch_mac_stream(e, av, pm, hi[a], pm, bslot0, nsum, a * e->nchunk);
-            swept = std::max(swept, hi[a]);
+        for (int a = 0; a < pl.nsweep; a++) {
+            ActiveVoice av = pl.sweep[a];
+            av.uniform = e->gain_change_block[av.v] + (uint64_t)pl.hi[a] <= blk && e->gain_change_block[av.v] < blk;
+            launch_mac_stream(e, av, pm, pl.hi[a], pm, bslot0, pl.nsum, a * e->nchunk);
+            swept = std::max(swept, pl.hi[a]);
         }
         if (timed) {
             HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], e->stream));
@@ -2081,49 +2077,133 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         }
         return MC_OK;
     };
-    bool spec_hit = e->spec_valid && e->spec_block == e->t_front && e->spec_nact == nsweep;
-    if (spec_hit)
-        for (int a = 0; a < nsweep && spec_hit; a++)
-            spec_hit = e->spec_vir[0][a] == st.ctx.vir[0][sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][sweep[a].v];
-    if (!spec_hit) {
-        if (nsweep) {
-            int rc = launch_mac(e->t_front);
-            if (rc) return rc;
-        } else {
-            HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)pm * MC_NB * nsum, e->stream));
+    auto sweep_or_zero = [&](const PPlan& pl, uint64_t blk) -> int {
+        if (pl.nsweep) return launch_mac(pl, blk);
+        HIP_TRY(hipMemsetAsync(e->d_part, 0, sizeof(float4) * (size_t)pm * MC_NB * pl.nsum, e->stream));
+        return MC_OK;
+    };
+    auto remember_sweep = [&](const PPlan& pl, const Staged& st, uint64_t blk) {
+        e->spec_valid = true;
+        e->spec_block = blk;
+        e->spec_nact = pl.nsweep;
+        for (int a = 0; a < pl.nsweep; a++) {
+            e->spec_vir[0][a] = st.ctx.vir[0][pl.sweep[a].v];
+            e->spec_vir[1][a] = st.ctx.vir[1][pl.sweep[a].v];
         }
-    }
-    e->spec_valid = false;
+    };
+    auto sweep_matches = [&](const PPlan& pl, const Staged& st, uint64_t blk) {
+        bool ok = e->spec_valid && e->spec_block == blk && e->spec_nact == pl.nsweep;
+        for (int a = 0; a < pl.nsweep && ok; a++)
+            ok = e->spec_vir[0][a] == st.ctx.vir[0][pl.sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][pl.sweep[a].v];
+        return ok;
+    };
+    auto launch_tail = [&](const Staged& st, const PPlan& pl, uint64_t blk, unsigned seq, bool parked) {
+        const int slot0 = (int)(blk & (uint64_t)(e->ring - 1));
+        const unsigned long long* bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
 #define MC_LAUNCH_TAILP(PM)                                                                                                  \
-    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, pin1, pin2, vset, e->Pstride, \
-                       e->d_fdl, e->d_slotgain, e->ring, slot0, e->d_part, nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr,  \
-                       e->d_cring, e->rc, st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)e->t_front,     \
-                       (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,      \
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, ++e->flag_seq, make_retired(e))
-    if (pm == 2)
-        MC_LAUNCH_TAILP(2);
-    else
-        MC_LAUNCH_TAILP(4);
+    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, pin1, pin2, pl.vset, e->Pstride, e->d_fdl, e->d_slotgain, \
+                       e->ring, slot0, e->d_part, pl.nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr, e->d_cring, e->rc,    \
+                       st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)blk, (int64_t)st.ctx.predelay,     \
+                       (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,                                \
+                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, seq, make_retired(e), bell,     \
+                       e->hd_exited, e->park_ticks)
+        if (pm == 2)
+            MC_LAUNCH_TAILP(2);
+        else
+            MC_LAUNCH_TAILP(4);
 #undef MC_LAUNCH_TAILP
-    HIP_TRY(hipGetLastError());
+    };
+    auto same_cc = [](const mc_cc_value& a, const mc_cc_value& b) {  // (field by field: the struct has padding)
+        return a.select == b.select && a.predelay == b.predelay && a.speed == b.speed && a.vsteps == b.vsteps && a.dry == b.dry &&
+               a.wet == b.wet && a.panDry == b.panDry && a.panWet == b.panWet && a.level == b.level;
+    };
+
+    // ---- this period: a parked tail staged with the same parameters, or the ordinary launches
+    Staged st;
+    PPlan pl;
+    unsigned my_seq = 0;
+    bool relaunch_ok = false;
+    const bool hit = e->pre.valid && e->pre.pm == pm && e->pre.block == e->t_front && same_cc(cc[0], e->pre.cc[0]) &&
+                     same_cc(cc[1], e->pre.cc[1]) && cc[0].predelay == e->cur_delay;
+    if (hit) {
+        my_seq = e->pre.seq;
+        ring_bell(e, my_seq, 0);
+        e->pre.valid = false;
+        st = e->pre.st;
+        make_pplan(st, pl);
+        relaunch_ok = true;
+        e->spec_valid = false;  // (its sweep has been consumed)
+    } else {
+        int rc = drain_post(e);
+        if (!rc) rc = leave_jack_path(e);
+        if (!rc) rc = retire_epoch(e, cc[0].predelay);
+        if (!rc) rc = stage_params(e, pm, cc, &st);
+        if (rc) return rc;
+        if (st.ctx.pstride != 0) return fail(MC_ERR_STATE, "the blocks of one period must share their parameters");
+        make_pplan(st, pl);
+        if (!sweep_matches(pl, st, e->t_front)) {
+            rc = sweep_or_zero(pl, e->t_front);
+            if (rc) return rc;
+        }
+        e->spec_valid = false;
+        my_seq = ++e->flag_seq;
+        launch_tail(st, pl, e->t_front, my_seq, false);
+        HIP_TRY(hipGetLastError());
+    }
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
     e->batch_seq++;
     e->t_front += (uint64_t)pm;
     e->t_abs = e->t_front;
-    if (e->speculate && nsweep) {
-        int rc = launch_mac(e->t_front);
+
+    // ---- the next period: its sweep in the shadow of this one (a speculation the next call checks), and - when nothing
+    // is moving - its tail behind the sweep, parked
+    if (e->speculate && pl.nsweep) {
+        int rc = launch_mac(pl, e->t_front);
         if (rc) return rc;
-        e->spec_valid = true;
-        e->spec_block = e->t_front;
-        e->spec_nact = nsweep;
-        for (int a = 0; a < nsweep; a++) {
-            e->spec_vir[0][a] = st.ctx.vir[0][sweep[a].v];
-            e->spec_vir[1][a] = st.ctx.vir[1][sweep[a].v];
+        remember_sweep(pl, st, e->t_front);
+    }
+    if (e->park && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half && params_steady(e, cc) &&
+        cc[0].predelay == e->cur_delay) {
+        Staged st_next;
+        int rc = stage_params(e, pm, cc, &st_next);  // (steady: advancing the cross-fade by a call changes nothing)
+        if (rc) return rc;
+        PPlan pl_next;
+        make_pplan(st_next, pl_next);
+        if (st_next.ctx.pstride == 0 && std::memcmp(&st_next.first, &st.first, sizeof(BlockParams)) == 0 &&
+            (pl_next.nsweep == 0 || sweep_matches(pl_next, st_next, e->t_front))) {
+            if (!pl_next.nsweep) {
+                rc = sweep_or_zero(pl_next, e->t_front);
+                if (rc) return rc;
+            }
+            const unsigned seq = ++e->flag_seq;
+            launch_tail(st_next, pl_next, e->t_front, seq, true);
+            HIP_TRY(hipGetLastError());
+            e->pre.valid = true;
+            e->pre.pm = pm;
+            e->pre.block = e->t_front;
+            e->pre.seq = seq;
+            e->pre.cc[0] = cc[0];
+            e->pre.cc[1] = cc[1];
+            e->pre.st = st_next;
+            e->pre.carries_sweep = false;
         }
     }
-    {
-        int rc = wait_period(e, e->flag_seq);
+    for (;;) {
+        int rc = wait_period(e, my_seq);
+        if (rc == MC_OK) break;
+        if (rc != 1) return rc;
+        // the parked tail gave up on its own (the host was away for more than park_ms): the same period the ordinary way.
+        // What was queued behind it worked on a delay line without this period: the next period's parked tail is told to
+        // give up, its sweep is forgotten, and this period's own partial sums are summed again (the sweep behind overwrote them)
+        if (!relaunch_ok) return fail(MC_ERR_HIP, "period did not complete");
+        relaunch_ok = false;
+        unpark(e);
+        e->spec_valid = false;
+        rc = sweep_or_zero(pl, e->t_front - (uint64_t)pm);
         if (rc) return rc;
+        my_seq = ++e->flag_seq;
+        launch_tail(st, pl, e->t_front - (uint64_t)pm, my_seq, false);
+        HIP_TRY(hipGetLastError());
     }
     std::memcpy(outL, e->h_io + 2 * cap, bytes);
     std::memcpy(outR, e->h_io + 3 * cap, bytes);

@@ -1724,35 +1724,39 @@ def test_q4_output_clamp_parts_from_the_reference_only_after_saturation(oracle_m
         assert np.abs(got - ref).max() > 0.3  # and differs where the reference's partial sums saturated
 
 
-def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib, monkeypatch):
-    """The JACK path launches the next period one call ahead and parks it on a doorbell (process_one).  A host that
-    pauses longer than the park time (here 20 ms) finds that the parked tail gave up and launches the period again;
-    controller changes, a batch call, an IR reload and a reset in between tell the parked period to give up; the
-    samples are the oracle's throughout.  MCCONV_NO_PARK=1 (every period launched on arrival) gives the same bits."""
+@pytest.mark.parametrize("period", [256, 512, 1024])
+def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib, monkeypatch, period):
+    """The JACK path launches the next period one call ahead and parks it on a doorbell (process_one; for 512- and
+    1024-frame periods process_period_fused, behind the period's sweep).  A host that pauses longer than the park time
+    (here 20 ms) finds that the parked tail gave up and launches the period again; controller changes, a batch call, an
+    IR reload and a reset in between tell the parked period to give up; the samples are the oracle's throughout.
+    MCCONV_NO_PARK=1 (every period launched on arrival) gives the same bits."""
     import time
 
     from cuda_audio_amd.synth import make_input, make_ir
 
-    n_ref, nb = 8192, 120
-    x = make_input(nb * 256, seed=31)
+    n_ref, ncalls = 8192, 120
+    batch = 8 * 256  # frames of the batch call in between
+    total = (ncalls - 0) * period + batch
+    x = make_input(total, seed=31)
     irs = [make_ir(6000, seed=61, norm=0.05), make_ir(5000, seed=63, norm=0.05)]
     p0, p1 = dict(BASE, select=0, wet=0.6), dict(BASE, select=1, level=0.9)
     ref = oracle_mod.RefCompat(n_ref, True)
     for i, ir in enumerate(irs):
         ref.prepare(i, ir)
     apply_params(ref, p0, p1, True)
-    want = np.zeros((2, nb * 256))
+    want = np.zeros((2, total))
 
     def stream(c, with_pauses):
-        got = np.zeros((2, nb * 256), np.float32)
-        b = 0
+        got = np.zeros((2, total), np.float32)
+        pos = 0
 
         def periods(n):
-            nonlocal b
+            nonlocal pos
             for _ in range(n):
-                s = slice(b * 256, (b + 1) * 256)
+                s = slice(pos, pos + period)
                 got[:, s] = np.stack(c.onProcess(x[0, s], x[1, s]))
-                b += 1
+                pos += period
 
         periods(40)                      # the cold-start ramp converges: periods start to be parked
         if with_pauses:
@@ -1760,24 +1764,25 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
         periods(10)
         c.cc[0].value.wet = 0.3          # a controller moves: the parked period was staged with the old value
         periods(10)
-        s = slice(b * 256, (b + 8) * 256)
+        s = slice(pos, pos + batch)
         got[:, s] = c.process(x[0, s], x[1, s])  # a batch call in between (max_batch 8)
-        b += 8
+        pos += batch
         periods(20)
         c.prepare(1, irs[1])             # an IR reload (same taps): the parked tail had its spectra loaded already
         periods(12)
         if with_pauses:
             time.sleep(0.06)
-        periods(nb - b)
+        periods(ncalls - 92)
+        assert pos == total
         return got
 
     # the oracle sees the same events at the same periods
     o = 0
-    for n, ev in ((50, None), (nb - 50, "wet")):
+    for n, ev in ((50 * period, None), (total - 50 * period, "wet")):
         if ev == "wet":
             ref.set(0, wet=0.3)
-        s = slice(o * 256, (o + n) * 256)
-        want[:, s] = ref.process(x[0, s], x[1, s])
+        s = slice(o, o + n)
+        want[:, s] = ref.process(x[0, s], x[1, s], block=period)
         o += n
     outs = []
     for park in (True, False):
@@ -1786,7 +1791,7 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
             monkeypatch.delenv("MCCONV_NO_PARK", raising=False)
         else:
             monkeypatch.setenv("MCCONV_NO_PARK", "1")
-        c = _conv(fftSize=n_ref, max_batch=8)
+        c = _conv(fftSize=n_ref, max_batch=8, period=period)
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
         apply_params(c, p0, p1, False)
