@@ -496,8 +496,12 @@ def main():
         xs, d_in = make_inputs(T)
         d_out = [torch.zeros(2, T * BLOCK, device=dev) for _ in range(npairs)]
         torch.cuda.synchronize()
-        for e in eng:
-            e.use_torch_stream(comp)
+        # several pairs (config 4 on one GPU): each Convolution object on a stream of its own, as the reference's instances
+        # are (conv.cu:147-150 creates four streams per object) - one pair's launches fill the CUs another's drain
+        # (BENCH_ONE_STREAM=1: all on the compute stream)
+        pair_streams = [comp] if (npairs == 1 or os.environ.get("BENCH_ONE_STREAM")) else [torch.cuda.Stream(device=dev) for _ in range(npairs)]
+        for p, e in enumerate(eng):
+            e.use_torch_stream(pair_streams[p % len(pair_streams)])
 
         def step(k):
             o = (k % n_distinct) * T * BLOCK
