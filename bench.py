@@ -573,8 +573,9 @@ def main():
                 "rtf": round(nb * BLOCK / FS / dth, 1), "ms_per_block_batch": round(dth / nst * 1e3, 4), "blocks": nb,
                 "pcie_GBps_in": round(nb * 2 * BLOCK * 4 / dth / 1e9, 2), "pcie_GBps_out": round(nb * 2 * BLOCK * 4 / dth / 1e9, 2),
                 "note": "mc_process_batch with pinned host buffers (mc_host_alloc): one call over %d blocks, chunks of the "
-                        "engine's preferred batch, H2D / kernels / D2H of consecutive chunks on three streams; returns when the "
-                        "last output byte is in host memory. Never `value`." % nb,
+                        "engine's preferred batch, the copy-in of the next chunk under the kernels of the current one, whose last "
+                        "kernel stores the output straight into the caller's pinned buffer; returns when the last output byte is "
+                        "in host memory. Never `value`." % nb,
             }
             e.use_torch_stream(comp)
 

@@ -251,6 +251,7 @@ struct mc_engine {
     // (MCCONV_BAR_IO=0: mapped host memory as before).  16 floats = the doorbell's line, then in1, in2 (room for 1024 frames each).
     float* d_bar = nullptr;
     bool bar_io = false;
+    bool host_out_direct = true;  // MCCONV_HOST_OUT_DIRECT=0: pinned-buffer batches copy their output out instead of storing it to the host
     unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
     unsigned* hd_exited = nullptr;
 #ifdef MC_JACK_TRACE
@@ -1946,6 +1947,20 @@ int process_host_pinned(mc_engine* e, const float* in1, const float* in2, float*
         HIP_TRY(hipMemcpyAsync(d[1], in2 + off, bytes, hipMemcpyHostToDevice, e->h2d_stream));
         HIP_TRY(hipEventRecord(e->ev_h2d[b], e->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+        if (e->host_out_direct) {
+            // the kernels that finish the output store it straight into the caller's pinned buffers (posted writes over the
+            // link): no copy-out, no second copy direction to take turns with the copy-in
+            float *hl = nullptr, *hr = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void**)&hl, outL + off, 0));
+            HIP_TRY(hipHostGetDevicePointer((void**)&hr, outR + off, 0));
+            int rc = run_front(e, d[0], d[1], n, nullptr, 0, n, hl, hr);
+            if (rc) return rc;
+            rc = run_back(e, d[0], d[1], nullptr, hl, hr, n);
+            if (!rc) rc = fence_post(e);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(e->ev_comp[b], e->stream));
+            continue;
+        }
         if (k >= 3) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_d2h[b], 0));
         int rc = run_front(e, d[0], d[1], n, nullptr, 0, n, d[2], d[3]);
         if (rc) return rc;
@@ -2392,6 +2407,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->h_exited = e->h_flag + 32;
     e->hd_exited = e->hd_flag + 32;
     if (std::getenv("MCCONV_NO_PARK")) e->park = false;
+    if (const char* ho = std::getenv("MCCONV_HOST_OUT_DIRECT")) e->host_out_direct = std::atoi(ho) != 0;
     {
         int large_bar = 0;
         const char* bi = std::getenv("MCCONV_BAR_IO");
