@@ -627,13 +627,15 @@ def main():
                 "rtf_period_spaced": round(BLOCK / FS / spaced, 1),
                 "avg_runtime_ms": round(e.avgRuntime(), 5),
                 "mac_kernel": "k_mac_stream (every block re-reads 4 IR paths + 2 delay-line inputs: the literal partition x bin MAC)",
-                "mac_kernel_us_event_bracketed": round(k_ms * 1e3, 2),
-                "mac_algorithmic_GBps": round(ab / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
-                "mac_frac_of_hbm_peak": round(ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                "mac_kernel_span_us": round(k_ms * 1e3, 2),
+                "mac_kernel_timed_with": "time stamps inside the kernel: first workgroup start to last workgroup end (100 MHz counter), in a "
+                                         "separate pass with every period launched on arrival. rocprofv3's duration of the same launch "
+                                         "(dispatch and completion included) is 4.1-4.3 us: profiles/r2_jack_summary.md",
+                "mac_algorithmic_GBps_over_span": round(ab / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                "mac_frac_of_hbm_peak_over_span": round(ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
                 "note": "all values measured in this run. us_per_block_wall: calls back to back; us_per_call_period_spaced: 500 us idle "
                         "between calls, as under jackd (the next period's tail is launched one call ahead and parked on a doorbell). "
-                        "The event-bracketed sweep is measured in a separate pass with every period launched on arrival (the events add "
-                        "~3 us of their own). The "
+                        "The "
                         "21 MB working set is re-read every period and is served by L2 / Infinity Cache, not HBM "
                         "(FETCH_SIZE of this launch: profiles/)",
             }

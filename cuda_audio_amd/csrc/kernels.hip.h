@@ -613,14 +613,28 @@ __device__ __forceinline__ void mac_stream_body(const int bin, const int ch, con
     }
 }
 
+#define MC_STAMP_WGS 2048  // workgroups of a launch that leave time stamps (k_mac_stream)
 template <bool UNIFORM, int NT, bool HALF>
 __global__ __launch_bounds__(NT) void k_mac_stream(const void* __restrict__ H0v, const void* __restrict__ H1v,
                                                    int pstride_ir, int p_begin, int p_end, int chunk,
                                                    const void* __restrict__ fdlv, const float4* __restrict__ slotgain,
                                                    int ring, int slot0, float4* __restrict__ part, int nsum, int ch_off,
-                                                   float4 ugain, float2 inv) {
+                                                   float4 ugain, float2 inv, unsigned long long* __restrict__ stamps) {
+    // stamps != null (kernel timing of a single period's sweep, whose few microseconds HIP events cannot bracket): every
+    // workgroup leaves {start, end} in ticks of the 100 MHz counter in its own slot (no atomics: 512 of them on one
+    // address cost more than the kernel); the host takes the earliest start and the latest end
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned long long t_start = 0;
+    if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
     mac_stream_body<UNIFORM, NT, HALF>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, H0v, H1v, pstride_ir, p_begin, p_end, chunk, fdlv,
                                        slotgain, ring, slot0, part, nsum, ch_off, ugain, inv);
+    if (stamps && wg < MC_STAMP_WGS) {
+        __syncthreads();  // (every wave's stores have been issued and acknowledged)
+        if (threadIdx.x == 0) {
+            stamps[2 * wg] = t_start;
+            stamps[2 * wg + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -47,6 +47,7 @@ constexpr int kMixIrs = 4;  // merged spectra of deselected IRs: [half][buffer],
 constexpr int kStageBufs = 4;
 constexpr int kEvPool = 1024;
 constexpr int kPipe = 2;
+constexpr int kStampSlots = 64;  // timed launches between two drains whose kernels leave their own time stamps
 
 inline uint32_t next_pow2(uint64_t v) {
     uint32_t p = 1;
@@ -284,6 +285,8 @@ struct mc_engine {
     bool ktiming = false;
     hipEvent_t kev[kEvPool][2];
     uint32_t kev_blocks[kEvPool];
+    bool kev_stamped[kEvPool];            // the launch carries in-kernel time stamps (a single period's sweep)
+    unsigned long long* d_stamps = nullptr;  // [kStampSlots][MC_STAMP_WGS][2] {start, end} per workgroup in 100 MHz ticks
     int kev_n = 0;
     bool kev_created = false;
     mc_kernel_stats ks;
@@ -326,13 +329,36 @@ int leave_jack_path(mc_engine* e) {
     return MC_OK;
 }
 
+hipError_t reset_stamps(mc_engine* e) {
+    return hipMemset(e->d_stamps, 0, sizeof(unsigned long long) * 2 * MC_STAMP_WGS * kStampSlots);
+}
+
 int drain_kernel_events(mc_engine* e) {
     if (!e->kev_n) return MC_OK;
     unpark(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<unsigned long long> stamps;
+    bool any_stamped = false;
+    for (int i = 0; i < e->kev_n; i++) any_stamped = any_stamped || e->kev_stamped[i];
+    if (any_stamped && e->d_stamps) {
+        stamps.resize((size_t)2 * MC_STAMP_WGS * kStampSlots);
+        HIP_TRY(hipMemcpy(stamps.data(), e->d_stamps, sizeof(unsigned long long) * stamps.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(reset_stamps(e));
+    }
     for (int i = 0; i < e->kev_n; i++) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->kev[i][0], e->kev[i][1]));
+        if (e->kev_stamped[i] && !stamps.empty() && i < kStampSlots) {
+            unsigned long long lo = ~0ull, hi = 0;
+            const unsigned long long* sp = stamps.data() + (size_t)2 * MC_STAMP_WGS * i;
+            for (int w = 0; w < MC_STAMP_WGS; w++)
+                if (sp[2 * w]) {
+                    lo = std::min(lo, sp[2 * w]);
+                    hi = std::max(hi, sp[2 * w + 1]);
+                }
+            if (hi > lo) ms = (float)((double)(hi - lo) * 1e-5);  // 100 MHz ticks -> ms
+        }
+        e->kev_stamped[i] = false;
         e->ks.launches++;
         e->ks.blocks += e->kev_blocks[i];
         e->ks.total_ms += ms;
@@ -737,7 +763,7 @@ void partition_range(const mc_engine* e, int p_hi, int* p_begin, int* p_end) {
 }
 
 void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, int T, int slot0, int nsum, int ch_off,
-                       float4* dst = nullptr) {
+                       float4* dst = nullptr, unsigned long long* stamps = nullptr) {
     if (!dst) dst = e->d_part;
     const hipStream_t st = e->stream;
     const int nt = e->stream_nt;
@@ -752,7 +778,7 @@ void launch_mac_stream(mc_engine* e, const ActiveVoice& a, int p_lo, int p_hi, i
     const float2 inv = make_float2(1.0f / (a.ir0->scale16 * FDL16_SCALE), 1.0f / (a.ir1->scale16 * FDL16_SCALE));
 #define MC_LAUNCH_STREAM(U, NT, H)                                                                                        \
     hipLaunchKernelGGL((k_mac_stream<U, NT, H>), grid, dim3(NT), 0, st, h0, h1, e->Pstride, p_lo, p_hi, chunk, fd, sg, \
-                       e->ring, slot0, dst, nsum, ch_off, a.ugain, inv)
+                       e->ring, slot0, dst, nsum, ch_off, a.ugain, inv, stamps)
 #define MC_LAUNCH_STREAM_H(U, NT) \
     do {                          \
         if (half)                 \
@@ -1634,19 +1660,21 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             return MC_OK;
         }
         if (e->ktiming) {
-            if (e->kev_n == kEvPool) {
+            if (e->kev_n >= kStampSlots) {
                 int rc = drain_kernel_events(e);
                 if (rc) return rc;
             }
             e->kev_blocks[e->kev_n] = 1;
+            e->kev_stamped[e->kev_n] = true;
             HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
         }
+        unsigned long long* stamps = e->ktiming ? e->d_stamps + (size_t)2 * MC_STAMP_WGS * e->kev_n : nullptr;
         const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
         int swept = 0;
         for (int a = 0; a < pl.nsweep; a++) {
             ActiveVoice av = pl.sweep[a];
             av.uniform = sweep_uniform(av, pl.hi[a], blk);
-            launch_mac_stream(e, av, pl.lo[a], pl.hi[a], 1, bslot0, pl.nsum, a * e->nchunk, dst);
+            launch_mac_stream(e, av, pl.lo[a], pl.hi[a], 1, bslot0, pl.nsum, a * e->nchunk, dst, stamps);
             swept = std::max(swept, pl.hi[a] - (pl.lo[a] == 2 ? 0 : pl.lo[a]));
         }
         if (e->ktiming) {
@@ -2069,19 +2097,21 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     auto launch_mac = [&](const PPlan& pl, uint64_t blk) -> int {
         const bool timed = e->ktiming;
         if (timed) {
-            if (e->kev_n == kEvPool) {
+            if (e->kev_n >= kStampSlots) {
                 int rc = drain_kernel_events(e);
                 if (rc) return rc;
             }
             e->kev_blocks[e->kev_n] = (uint32_t)pm;
+            e->kev_stamped[e->kev_n] = true;
             HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], e->stream));
         }
+        unsigned long long* stamps = timed ? e->d_stamps + (size_t)2 * MC_STAMP_WGS * e->kev_n : nullptr;
         const int bslot0 = (int)(blk & (uint64_t)(e->ring - 1));
         int swept = 0;
         for (int a = 0; a < pl.nsweep; a++) {
             ActiveVoice av = pl.sweep[a];
             av.uniform = e->gain_change_block[av.v] + (uint64_t)pl.hi[a] <= blk && e->gain_change_block[av.v] < blk;
-            launch_mac_stream(e, av, pm, pl.hi[a], pm, bslot0, pl.nsum, a * e->nchunk);
+            launch_mac_stream(e, av, pm, pl.hi[a], pm, bslot0, pl.nsum, a * e->nchunk, nullptr, stamps);
             swept = std::max(swept, pl.hi[a]);
         }
         if (timed) {
@@ -2517,6 +2547,7 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_cring);
     (void)hipFree(e->d_ctot);
     (void)hipFree(e->d_cflag);
+    (void)hipFree(e->d_stamps);
     (void)hipFree(e->d_done_ctr);
     (void)hipFree(e->d_res_mac);
     (void)hipFree(e->d_res_fix);
@@ -2824,7 +2855,10 @@ int mc_enable_kernel_timing(mc_engine* e, int on) {
         for (int i = 0; i < kEvPool; i++) {
             HIP_TRY(hipEventCreate(&e->kev[i][0]));
             HIP_TRY(hipEventCreate(&e->kev[i][1]));
+            e->kev_stamped[i] = false;
         }
+        HIP_TRY(hipMalloc(&e->d_stamps, sizeof(unsigned long long) * 2 * MC_STAMP_WGS * kStampSlots));
+        HIP_TRY(reset_stamps(e));
         e->kev_created = true;
     }
     if (!on) {

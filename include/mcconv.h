@@ -99,7 +99,9 @@ typedef struct {
 typedef struct {
     uint64_t launches;      /* MAC-kernel launches timed so far */
     uint64_t blocks;        /* blocks those launches processed */
-    double total_ms;        /* sum of HIP-event durations of those launches */
+    double total_ms;        /* sum of the durations of those launches: HIP events around the launch; for the sweep of a
+                               single period (a few microseconds) the kernel's own time stamps, first workgroup start to
+                               last workgroup end */
     double last_ms;
     uint32_t resident;      /* 1 = the last launch used the resident (batch) kernel */
     uint32_t partitions;    /* partitions swept per block by the last launch */
