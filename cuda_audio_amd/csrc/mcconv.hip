@@ -1609,6 +1609,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     if (e->bar_io) {
         std::memcpy(e->d_bar + 16, in1, sizeof(float) * MC_B);
         std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, sizeof(float) * MC_B);
+        _mm_sfence();  // (write-combined stores: out of the buffers before a doorbell or a launch can refer to them)
     } else {
         std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
         std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
