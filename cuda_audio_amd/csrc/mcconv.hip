@@ -2376,6 +2376,18 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
         std::memset(e->h_flag, 0, 256);
         if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
+        {  // the period through the BAR where the CPU can write device memory (see mc_engine::d_bar)
+            int large_bar = 0;
+            const char* bi = std::getenv("MCCONV_BAR_IO");
+            if ((!bi || std::atoi(bi) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large_bar &&
+                hipExtMallocWithFlags((void**)&e->d_bar, 16384, hipDeviceMallocFinegrained) == hipSuccess) {
+                ENG_TRY(hipMemset(e->d_bar, 0, 16384));
+                e->bar_io = true;
+            } else {
+                (void)hipGetLastError();
+                e->d_bar = nullptr;
+            }
+        }
         int rc = sf_create(e);
         if (rc) {
             mc_destroy(e);

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64 * SF_ROWS) void k_sf_fwdmac(SfCall C, int N, int
         for (int r = 0; r < 8; r++) {
             float2 acc = make_float2(0.f, 0.f);
             for (int n = lane + 64 * r; n < C.nframes; n += FFT_N) {  // (the pass over b folded into the input)
-                const float x = in[n];
+                // (system scope: the period may sit in device memory the CPU wrote through the BAR)
+                const float x = __hip_atomic_load(in + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const float2 w = sf_cis(((unsigned)d * (unsigned)n) & (unsigned)(N - 1), N, -1.f);
                 acc.x += x * w.x;
                 acc.y += x * w.y;
@@ -204,7 +205,8 @@ __device__ __forceinline__ size_t sf_slot(const SfCall& C, int M, unsigned s) { 
 
 // out = acc + dry mix for a frame of the period; its slot becomes the far end of the accumulator: the reference shifts zeros in
 __device__ __forceinline__ void sf_emit(const SfCall& C, unsigned s, float l, float r) {
-    const float x1 = C.in1[s], x2 = C.in2[s];
+    const float x1 = __hip_atomic_load(C.in1 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float x2 = __hip_atomic_load(C.in2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     C.outL[s] = l + (x1 * C.dry[0][0] + x2 * C.dry[0][1]);
     C.outR[s] = r + (x1 * C.dry[1][0] + x2 * C.dry[1][1]);
 }

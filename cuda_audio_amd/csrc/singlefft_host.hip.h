@@ -172,9 +172,18 @@ inline int sf_batch_host(mc_engine* e, const float* in1, const float* in2, float
 inline int sf_process(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR) {
     const int nf = e->pm * MC_B;
     const size_t cap = (size_t)e->Thost * MC_B;
-    std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * nf);
-    std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * nf);
-    int rc = sf_call(e, e->hd_io + 0 * cap, e->hd_io + 1 * cap, e->hd_io + 2 * cap, e->hd_io + 3 * cap, nf, e->spin_wait);
+    const float *pin1 = e->hd_io + 0 * cap, *pin2 = e->hd_io + 1 * cap;
+    if (e->bar_io) {  // straight into device memory through the BAR (write-combined: fenced before the launches)
+        std::memcpy(e->d_bar + 16, in1, sizeof(float) * nf);
+        std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, sizeof(float) * nf);
+        _mm_sfence();
+        pin1 = e->d_bar + 16;
+        pin2 = e->d_bar + 16 + 4 * MC_B;
+    } else {
+        std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * nf);
+        std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * nf);
+    }
+    int rc = sf_call(e, pin1, pin2, e->hd_io + 2 * cap, e->hd_io + 3 * cap, nf, e->spin_wait);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     if (e->spin_wait) {  // the last workgroup publishes the sequence number once the period is in h_io
