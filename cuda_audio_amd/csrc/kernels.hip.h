@@ -2736,7 +2736,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// Second-level transform, fused form for uniform gains and IRs up to 2560
+// Second-level transform, fused form for uniform gains and IRs up to 5632
 // partitions: transforms of 8192 points, so that the spectra of BOTH input
 // sequences of a (bin, chunk) fit in LDS side by side (2 x 66.5 KB).  One
 // workgroup reads the delay-line window once (16 bytes per slot: both inputs),

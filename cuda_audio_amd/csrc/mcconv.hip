@@ -264,6 +264,9 @@ struct mc_engine {
     bool fft2_fused = true;  // ... in the fused 8192-point form where it applies
     bool debug_addr = false;  // MCCONV_DEBUG_ADDR: print the device ranges k_g2_mac touches at its first launch (fault triage)
     int g2_grid = 1 << 30;   // workgroups of k_g2_mac, capped by the number of (bin, chunk) items (default: one per item); MCCONV_G2_GRID
+    int g2_pmax = 5632;      // longest block-axis convolution (partitions) the fused 8192-point form takes (MCCONV_G2_PMAX):
+                             // measured crossover with the split 16384-point form ~5700 (30 s IRs, P = 5168: 0.25 vs 0.27 ms
+                             // for a third more blocks)
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
     bool fuse_out = true;    // MCCONV_FUSE_OUT=0: the output always through k_post (measurement)
     unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
@@ -920,7 +923,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
             // transform gain(slot) x input for every voice and path
             bool per_slot = per_slot_gains;
             for (int a = 0; a < nact; a++) per_slot = per_slot || !act[a].uniform;
-            if (!per_slot && e->fft2_fused && pmax <= 2560) {
+            if (!per_slot && e->fft2_fused && pmax <= e->g2_pmax) {
                 // fused form: both inputs' 8192-point spectra side by side in LDS, no stash (k_g2_mac)
                 for (int a = 0; a < nact; a++) {
                     int rc = ensure_g2(e, act[a].ir0);
@@ -2489,6 +2492,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
+    if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
@@ -2930,7 +2934,7 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
     }
     uint64_t chunk = 0;
     if (e->fft2 && !e->half && (shard ? pmax >= 16 : pmax >= 256)) {
-        if (e->fft2_fused && pmax <= 2560) chunk = (uint64_t)(G2_N - pmax + 1);
+        if (e->fft2_fused && pmax <= e->g2_pmax) chunk = (uint64_t)(G2_N - pmax + 1);
         else if (pmax <= F2_N / 2) chunk = (uint64_t)(F2_N - pmax + 1);
     }
     if (!chunk || at_most < chunk) return at_most >= 8 ? (at_most & ~(uint64_t)7) : at_most;

@@ -1402,7 +1402,12 @@ def test_preferred_batch_length(gpu_lib, monkeypatch):
     assert c.preferred_batch(10 ** 9) == (6 * 6465 - 1) // 8 * 8  # capped by max_batch = 40000
     c.close()
     c = _conv(fftSize=2097152, max_batch=40000)
-    c.prepare(0, make_ir(1323000, seed=2))  # 5168 partitions: the 16384-point form, chunks of 11217
+    c.prepare(0, make_ir(1323000, seed=2))  # 5168 partitions: still the fused form, chunks of 8192 - 5168 + 1 = 3025
+    assert c.preferred_batch(32768) == (10 * 3025 - 1) // 8 * 8
+    c.close()
+    monkeypatch.setenv("MCCONV_FFT2_FUSED", "0")  # the 16384-point form: chunks of 11217
+    c = _conv(fftSize=2097152, max_batch=40000)
+    c.prepare(0, make_ir(1323000, seed=2))
     assert c.preferred_batch(32768) == (2 * 11217 - 1) // 8 * 8
     c.close()
 
@@ -1471,14 +1476,16 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
 
 
-@pytest.mark.parametrize("n_ref,taps,level,direct_cmp", [(524288, 441000, 254, True), (2097152, 1323000, 255, False)],
-                         ids=["P1723_fused", "P5168_split"])
+@pytest.mark.parametrize("n_ref,taps,level,direct_cmp", [(524288, 441000, 254, True), (2097152, 1323000, 255, False),
+                                                         (2097152, 1323000, 254, False)],
+                         ids=["P1723_fused", "P5168_split", "P5168_fused"])
 def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, level, direct_cmp):
     """The launch bench.py times, compared DIRECTLY with the oracle (conv.cu:392-401 restated as the partitioned sum,
     oracle.Upols.range): device-resident batches of mc_preferred_batch(32768) blocks - 32320 = five whole chunks of
     the fused 8192-point second-level transform for the 10 s IR, five items per persistent workgroup with window
     look-ahead; 22432 = two chunks of the split 16384-point form for the 30 s IR - in steady state (second and third
-    batch of the stream).  Oracle blocks: inside chunk 0, across the first chunk boundary, the batch end and the
+    batch of the stream; the 30 s IR also through the fused form, ten chunks of 3025 blocks, which it takes by
+    default since round 2's kernel made it the faster one there).  Oracle blocks: inside chunk 0, across the first chunk boundary, the batch end and the
     first blocks of the next launch.  For the 10 s IR also the whole batch against the direct-form MAC."""
     import torch
 
@@ -1490,7 +1497,7 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
 
     def run(direct, T=None):
         monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")  # (the suite is also run with the measurement switches set)
-        monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
+        monkeypatch.setenv("MCCONV_FFT2_FUSED", "1" if level == 254 else "0")
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
         c = _conv(fftSize=n_ref, max_batch=32768)
         for i, ir in enumerate(irs):
@@ -1512,7 +1519,7 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         return x, T, out, levels
 
     x, T, got, levels = run(False)
-    assert T == (32320 if taps == 441000 else 22432)
+    assert T == (32320 if taps == 441000 else (30248 if level == 254 else 22432))
     assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
     chunk = (8192 if level == 254 else 16384) - (-(-((taps + 255) // 256) // 16) * 16) + 1
     assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
