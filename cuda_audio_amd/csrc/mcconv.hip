@@ -267,6 +267,8 @@ struct mc_engine {
     int g2_pmax = 5632;      // longest block-axis convolution (partitions) the fused 8192-point form takes (MCCONV_G2_PMAX):
                              // measured crossover with the split 16384-point form ~5700 (30 s IRs, P = 5168: 0.25 vs 0.27 ms
                              // for a third more blocks)
+    int g2_pmin = 16;        // shortest block-axis convolution (partitions, uniform gains) of an unsharded engine that takes the
+                             // second-level transform (MCCONV_G2_PMIN; round 1: 256)
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
     bool fuse_out = true;    // MCCONV_FUSE_OUT=0: the output always through k_post (measurement)
     unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
@@ -868,7 +870,9 @@ int block_axis_taps(const mc_engine* e, const ActiveVoice* act, int nact, int* p
 
 // Will launch_mac_batch take the second-level transform for this batch?
 bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per_slot_gains, int T) {
-    (void)per_slot_gains;  // both gain layouts are handled (uniform: 2 sequences per bin; per slot: 4 per voice)
+    // both gain layouts are handled (uniform: 2 sequences per bin, fused form; per slot: 4 per voice, split form)
+    bool per_slot = per_slot_gains;
+    for (int a = 0; a < nact; a++) per_slot = per_slot || !act[a].uniform;
     if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || nact <= 0 ||
         T < 768)  // measured crossover with the direct MAC: ~600 blocks (0.095 ms whatever the batch length)
         return false;
@@ -876,7 +880,9 @@ bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per
     if (e->cfg.part_begin || e->cfg.part_end)
         // a shard's direct MAC costs ~0.076 ns per block and partition, the transform ~0.1 ms per launch of <= 6465 blocks
         return taps >= 16 && taps <= F2_N / 2 && (int64_t)T * taps >= 1300000;
-    return taps >= 256 && taps <= F2_N / 2;
+    // uniform gains: the fused form costs ~0.1 ms per 32000 blocks whatever the taps - the direct MAC needs that much for its
+    // fixed part alone (measured: 0.14 / 0.18 / 0.27 / 0.44 ms at 16 / 44 / 87 / 173 partitions); per-slot gains: the split form, from 256
+    return taps >= (per_slot ? 256 : e->g2_pmin) && taps <= F2_N / 2;
 }
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
@@ -2492,6 +2498,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
+    if (const char* gm = std::getenv("MCCONV_G2_PMIN")) e->g2_pmin = std::max(16, std::atoi(gm));
     if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
@@ -2933,7 +2940,7 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
         pmax = pe - pb;
     }
     uint64_t chunk = 0;
-    if (e->fft2 && !e->half && (shard ? pmax >= 16 : pmax >= 256)) {
+    if (e->fft2 && !e->half && (shard ? pmax >= 16 : pmax >= e->g2_pmin)) {
         if (e->fft2_fused && pmax <= e->g2_pmax) chunk = (uint64_t)(G2_N - pmax + 1);
         else if (pmax <= F2_N / 2) chunk = (uint64_t)(F2_N - pmax + 1);
     }
