@@ -267,6 +267,7 @@ struct mc_engine {
     int g2_pmax = 5632;      // longest block-axis convolution (partitions) the fused 8192-point form takes (MCCONV_G2_PMAX):
                              // measured crossover with the split 16384-point form ~5700 (30 s IRs, P = 5168: 0.25 vs 0.27 ms
                              // for a third more blocks)
+    int64_t fft2_work = 300000;  // blocks x partitions from which a batch takes the fused second-level form (MCCONV_FFT2_WORK)
     int g2_pmin = 16;        // shortest block-axis convolution (partitions, uniform gains) of an unsharded engine that takes the
                              // second-level transform (MCCONV_G2_PMIN; round 1: 256)
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
@@ -873,16 +874,20 @@ bool fft2_applies(const mc_engine* e, const ActiveVoice* act, int nact, bool per
     // both gain layouts are handled (uniform: 2 sequences per bin, fused form; per slot: 4 per voice, split form)
     bool per_slot = per_slot_gains;
     for (int a = 0; a < nact; a++) per_slot = per_slot || !act[a].uniform;
-    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || nact <= 0 ||
-        T < 768)  // measured crossover with the direct MAC: ~600 blocks (0.095 ms whatever the batch length)
-        return false;
+    if (!(T >= e->stream_threshold && !e->half) || !e->fft2 || nact <= 0) return false;
     const int taps = block_axis_taps(e, act, nact, nullptr);
-    if (e->cfg.part_begin || e->cfg.part_end)
-        // a shard's direct MAC costs ~0.076 ns per block and partition, the transform ~0.1 ms per launch of <= 6465 blocks
-        return taps >= 16 && taps <= F2_N / 2 && (int64_t)T * taps >= 1300000;
-    // uniform gains: the fused form costs ~0.1 ms per 32000 blocks whatever the taps - the direct MAC needs that much for its
-    // fixed part alone (measured: 0.14 / 0.18 / 0.27 / 0.44 ms at 16 / 44 / 87 / 173 partitions); per-slot gains: the split form, from 256
-    return taps >= (per_slot ? 256 : e->g2_pmin) && taps <= F2_N / 2;
+    if (taps > F2_N / 2) return false;
+    const bool shard = e->cfg.part_begin || e->cfg.part_end;
+    if (!per_slot && e->fft2_fused && taps <= e->g2_pmax)
+        // Uniform gains, fused form: a launch costs ~39 us per chunk of 8192 - taps + 1 blocks whatever the taps; the direct
+        // MAC ~10 us + 0.078 ns per block and partition (and never less than ~40 us for the longest IRs: one workgroup
+        // sweeps its partitions in turn).  Measured (P = 1728 / 345 / 32): the transform wins from 128 / ~900 / ~9000
+        // blocks on - a product of ~300 000 (MCCONV_FFT2_WORK)
+        return taps >= (shard ? 16 : e->g2_pmin) && (int64_t)T * taps >= e->fft2_work;
+    // per-slot gains (or the fused form switched off): the split form, two launches and a stash
+    if (T < 768) return false;
+    if (shard) return taps >= 16 && (int64_t)T * taps >= 1300000;
+    return taps >= 256;
 }
 
 // Partition x bin MAC of T blocks starting at delay-line slot `slot0` for the given voices.
@@ -2498,6 +2503,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
+    if (const char* tm = std::getenv("MCCONV_FFT2_WORK")) e->fft2_work = std::max<int64_t>(1, std::atoll(tm));
     if (const char* gm = std::getenv("MCCONV_G2_PMIN")) e->g2_pmin = std::max(16, std::atoi(gm));
     if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
