@@ -18,6 +18,8 @@ CMD = {
     "cfg2": "bench.py --steps 20 --warmup 5 --taps 88200 --fft-size 131072",
     "cfg2_single": "bench.py --form single --steps 10 --warmup 2 --taps 88200 --fft-size 131072   (config 2 in the reference's own shape: one 131072-point transform per call)",
     "cfg5_fp32": "bench.py --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152",
+    "cfg5_split": "MCCONV_FFT2_FUSED=0 bench.py --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152   (config 5 through the split 16384-point form)",
+    "ir1s": "bench.py --steps 20 --warmup 5 --taps 44100 --fft-size 65536   (a 1 s IR, 173 partitions: the fused form since round 2)",
     "cfg5_fp16": "bench.py ... --taps 1323000 --fft-size 2097152 --precision fp16 --blocks 2048",
     "cfg5_stream32": "bench.py ... --taps 1323000 --fft-size 2097152 --mode stream --blocks 2048",
     "cfg3_direct_mac": "MCCONV_FFT2=0 MCCONV_FFA_LEVELS=0 bench.py --steps 10 --warmup 3 --blocks 8192",

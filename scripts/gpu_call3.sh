@@ -15,6 +15,8 @@ run cfg3_noprewarm_w200 --steps 20 --warmup 200 --prewarm-ms 0 --no-latency --no
 run cfg2 --steps 20 --warmup 5 --taps 88200 --fft-size 131072 --no-latency --no-host-io --cpu-seconds 5
 run cfg2_single --form single --steps 10 --warmup 2 --taps 88200 --fft-size 131072
 run cfg5_fp32 --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152 --no-latency --no-host-io --cpu-seconds 5
+MCCONV_FFT2_FUSED=0 run cfg5_split --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152 --no-latency --no-host-io --no-cpu-baseline
+run ir1s --steps 20 --warmup 5 --taps 44100 --fft-size 65536 --no-latency --no-host-io --no-cpu-baseline
 run cfg5_fp16 --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152 --precision fp16 --blocks 2048 --no-latency --no-host-io --no-cpu-baseline
 run cfg5_stream32 --steps 20 --warmup 5 --taps 1323000 --fft-size 2097152 --mode stream --blocks 2048 --no-latency --no-host-io --no-cpu-baseline
 MCCONV_FFT2=0 MCCONV_FFA_LEVELS=0 run cfg3_direct_mac --steps 10 --warmup 3 --blocks 8192 --no-latency --no-host-io --no-cpu-baseline
