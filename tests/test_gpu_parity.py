@@ -1909,3 +1909,82 @@ def test_batch_longer_than_the_riding_prefix_chain(oracle_mod, gpu_lib, monkeypa
     want = u.range(x[0], x[1], T - n, n)
     err = rms(outs[0][:, (T - n) * 256:] - want)
     assert err <= RMS_TOL, f"rms {err:.3e}"
+
+
+@pytest.mark.parametrize("seed,moving_predelay", [(1, False), (2, False), (3, False), (4, True), (5, True)])
+def test_random_mix_of_batch_lengths_and_single_periods(oracle_mod, gpu_lib, seed, moving_predelay):
+    """One stream through every path in random order: single periods (parked tails), batches below the streaming
+    threshold, resident-MAC batches, batches long enough for the fused second-level transform (output finished by the
+    inverse transforms), host and device buffers - with controller changes (dry / wet / pans / level) between calls.  Each path leaves the rings the next one reads (wet ring written only where it
+    can still be read, segment ring, prefix sums, delay line).  Fixed predelay (a multiple of four or not): against the
+    partitioned oracle, 26 000 blocks.  With IR selects (short cross-fades: per-slot gains, the split form) and predelay
+    changes as well (blocks already played keep their offset: retired epochs ring out under batches that then go through
+    k_post): against the single-transform restatement of conv.cu, which is slower, 13 000 blocks."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    if moving_predelay:
+        n_ref, total, long_lo, long_hi = 8192, 13000, 9400, 9900          # P = 28 -> 32: fused from 9375 blocks
+        irs = [make_ir(7000, seed=70, norm=0.05), make_ir(6500, seed=71, norm=0.05), make_ir(4000, seed=72, norm=0.05)]
+    else:
+        n_ref, total, long_lo, long_hi = 16384, 26000, 4700, 9000          # P = 59 -> 64: fused from 4688 blocks
+        irs = [make_ir(15000, seed=70, norm=0.05), make_ir(14000, seed=71, norm=0.05), make_ir(9000, seed=72, norm=0.05)]
+    sizes = []
+    while sum(sizes) < total:
+        kind = int(rng.integers(0, 5))
+        sizes.append([1, 1, int(rng.integers(2, 47)), int(rng.integers(48, 400)), int(rng.integers(long_lo, long_hi))][kind])
+        if kind < 2:
+            sizes += [1] * int(rng.integers(3, 12))  # runs of single periods: they park once nothing moves
+    nb = sum(sizes)
+    x = make_input(nb * 256, seed=100 + seed)
+    x[0] += 0.03
+    u = oracle_mod.RefCompat(n_ref, True) if moving_predelay else oracle_mod.Upols(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=10000)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+        c.prepare(i, ir)
+    pd0 = int(rng.choice([0, 64, 301, 1024]))
+    p0, p1 = dict(BASE, select=0, wet=0.6, predelay=pd0), dict(BASE, select=1, level=0.9)
+    apply_params(u, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    o = 0
+    for k, n in enumerate(sizes):
+        if k and rng.random() < 0.3:
+            half = int(rng.integers(0, 2))
+            what = int(rng.integers(0, 5 if moving_predelay else 3))  # (the partitioned oracle blends no IRs: no selects there)
+            if what == 0:
+                p = dict(dry=float(rng.uniform(0.1, 0.6)), panDry=float(rng.uniform(-1, 1)))
+            elif what == 1:
+                p = dict(wet=float(rng.uniform(0.2, 0.7)), panWet=float(rng.uniform(-1, 1)))
+            elif what == 2:
+                p = dict(level=float(rng.uniform(0.5, 1.0)))
+            elif what == 3:
+                sp = int(rng.integers(2, 30))
+                p = dict(select=int(rng.integers(0, 3)), speed=sp, vsteps=sp)
+            else:
+                half, p = 0, dict(predelay=int(rng.choice([0, 64, 300, 301, 1024, 4097])))
+            u.set(half, **p)
+            c.cc[half].value.update(**p)
+        s = slice(o * 256, (o + n) * 256)
+        want[:, s] = u.process(x[0, s], x[1, s])
+        if n == 1:
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        elif rng.random() < 0.5:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        else:
+            d_in = torch.from_numpy(x[:, s].copy()).to(dev)
+            d_out = torch.full((2, n * 256), float("nan"), device=dev)
+            c.process_device(d_in[0].data_ptr(), d_in[1].data_ptr(), d_out[0].data_ptr(), d_out[1].data_ptr(), n)
+            c.sync()
+            got[:, s] = d_out.cpu().numpy()
+        o += n
+    c.close()
+    assert np.isfinite(got).all()
+    assert np.abs(want).max() < 1.0  # (the wet sum stays inside the clamp: Q4)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"seed {seed}: rms {err:.3e} (signal {rms(want):.3e}), calls {len(sizes)}"
