@@ -54,9 +54,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=0,
-                    help="blocks per step (batch length T). 0 (default): what the engine prefers up to 32768 blocks "
-                         "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 32320 = 187.6 s "
-                         "of audio = five chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR")
+                    help="blocks per step (batch length T). 0 (default): what the engine prefers up to --max-blocks "
+                         "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 129280 = 750 s "
+                         "of audio = twenty chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR")
+    ap.add_argument("--max-blocks", type=int, default=131072,
+                    help="upper limit of the preferred batch length (per GPU; eight block-sliced ranks then share a global batch "
+                         "of 8 x 129280 blocks, inside mc_config.max_batch <= 1048576). Longer batches amortise the launches' "
+                         "ramps and tails: 892 k x at 32320 blocks, 970 k x at 64640, 1.0 M x at 129280")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
     ap.add_argument("--channels", type=int, default=2, choices=[2, 4, 6, 8],
@@ -315,9 +319,9 @@ def main():
     def preferred(pb=0, pe=0):
         if a.blocks > 0:
             return a.blocks
-        probe = Convolution("probe", a.fft_size, max_batch=32768, device=local, part_begin=pb, part_end=pe)
+        probe = Convolution("probe", a.fft_size, max_batch=a.max_blocks, device=local, part_begin=pb, part_end=pe)
         probe.prepare(0, make_ir(a.taps, seed=5678))
-        t = probe.preferred_batch(32768)
+        t = probe.preferred_batch(a.max_blocks)
         probe.close()
         return t
 

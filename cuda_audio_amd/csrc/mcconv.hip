@@ -2308,7 +2308,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (cfg->struct_size != sizeof(mc_config)) return fail(MC_ERR_ARG, "mc_config size mismatch (%u vs %zu)", cfg->struct_size, sizeof(mc_config));
     if (cfg->n_ref < 4096 || (cfg->n_ref & (cfg->n_ref - 1))) return fail(MC_ERR_ARG, "n_ref must be a power of two >= 4096");
     if (cfg->n_ref > (1ull << 26)) return fail(MC_ERR_ARG, "n_ref too large");
-    if (cfg->max_batch < 1 || cfg->max_batch > 262144) return fail(MC_ERR_ARG, "max_batch must be in [1, 262144]");
+    if (cfg->max_batch < 1 || cfg->max_batch > 1048576) return fail(MC_ERR_ARG, "max_batch must be in [1, 1048576]");
     if ((cfg->part_begin % 16) || (cfg->part_end % 16)) return fail(MC_ERR_ARG, "partition shard bounds must be multiples of 16");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

@@ -58,7 +58,8 @@ typedef struct {
     int32_t device;         /* HIP device ordinal; -1 = current device */
     uint64_t n_ref;         /* the reference's fftSize (conv.h:52): IR truncation n_ref-1024
                                (conv.cu:239), Q1/Q2 window and 1/n_ref factors */
-    uint32_t max_batch;     /* largest nblocks accepted by the device-buffer batch calls (1..262144) */
+    uint32_t max_batch;     /* largest nblocks accepted by the device-buffer batch calls (1..1048576; the engine's rings and
+                               scratch are sized by it: about 33 KB of device memory per block) */
     uint32_t max_partitions;/* 0 = derive from n_ref: ceil((n_ref-1024)/256) */
     uint32_t compat;        /* 1 = bug-compatible with conv.cu (DC/Nyquist terms Q1/Q2);
                                0 = plain linear convolution */

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 CMD = {
     "cfg3": "bench.py --steps 20 --warmup 5   (the driver's command)",
+    "cfg3_T32320": "bench.py --steps 20 --warmup 5 --blocks 32320   (the step of the earlier records: five chunks)",
     "cfg3_long": "bench.py --steps 200 --warmup 20   (bench.py's own defaults)",
     "cfg3_noprewarm": "bench.py --steps 20 --warmup 5 --prewarm-ms 0",
     "cfg3_noprewarm_w200": "bench.py --steps 20 --warmup 200 --prewarm-ms 0",

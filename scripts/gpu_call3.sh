@@ -9,6 +9,7 @@ bash scripts/profile_jack.sh || true
 echo "== bench lines"
 run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/bench_$n.json 2> gpurun_out/bench_$n.err; echo "$n rc=$?"; }
 run cfg3 --steps 20 --warmup 5
+run cfg3_T32320 --steps 20 --warmup 5 --blocks 32320 --no-latency --no-host-io --no-cpu-baseline
 run cfg3_long --steps 200 --warmup 20
 run cfg3_noprewarm --steps 20 --warmup 5 --prewarm-ms 0 --no-latency --no-host-io --no-cpu-baseline
 run cfg3_noprewarm_w200 --steps 20 --warmup 200 --prewarm-ms 0 --no-latency --no-host-io --no-cpu-baseline

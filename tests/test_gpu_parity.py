@@ -1476,11 +1476,13 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
 
 
-@pytest.mark.parametrize("n_ref,taps,level,direct_cmp", [(524288, 441000, 254, True), (2097152, 1323000, 255, False),
-                                                         (2097152, 1323000, 254, False)],
-                         ids=["P1723_fused", "P5168_split", "P5168_fused"])
-def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, level, direct_cmp):
-    """The launch bench.py times, compared DIRECTLY with the oracle (conv.cu:392-401 restated as the partitioned sum,
+@pytest.mark.parametrize("n_ref,taps,level,direct_cmp,at_most",
+                         [(524288, 441000, 254, True, 32768), (2097152, 1323000, 255, False, 32768),
+                          (2097152, 1323000, 254, False, 32768), (524288, 441000, 254, False, 131072)],
+                         ids=["P1723_fused", "P5168_split", "P5168_fused", "P1723_fused_bench_step"])
+def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, level, direct_cmp, at_most):
+    """The launch bench.py times (its step: mc_preferred_batch(131072) = 129296 blocks, twenty chunks - the last case),
+    compared DIRECTLY with the oracle (conv.cu:392-401 restated as the partitioned sum,
     oracle.Upols.range): device-resident batches of mc_preferred_batch(32768) blocks - 32320 = five whole chunks of
     the fused 8192-point second-level transform for the 10 s IR, five items per persistent workgroup with window
     look-ahead; 22432 = two chunks of the split 16384-point form for the 30 s IR - in steady state (second and third
@@ -1499,11 +1501,11 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")  # (the suite is also run with the measurement switches set)
         monkeypatch.setenv("MCCONV_FFT2_FUSED", "1" if level == 254 else "0")
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
-        c = _conv(fftSize=n_ref, max_batch=32768)
+        c = _conv(fftSize=n_ref, max_batch=at_most)
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
         apply_params(c, p0, p1, False)
-        T = T or c.preferred_batch(32768)
+        T = T or c.preferred_batch(at_most)
         x = make_input(3 * T * 256)
         d_in = torch.from_numpy(x).to(dev)
         d_out = torch.zeros(3, 2, T * 256, device=dev)
@@ -1519,7 +1521,7 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         return x, T, out, levels
 
     x, T, got, levels = run(False)
-    assert T == (32320 if taps == 441000 else (30248 if level == 254 else 22432))
+    assert T == ((129296 if at_most > 32768 else 32320) if taps == 441000 else (30248 if level == 254 else 22432))
     assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
     chunk = (8192 if level == 254 else 16384) - (-(-((taps + 255) // 256) // 16) * 16) + 1
     assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
