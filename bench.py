@@ -312,7 +312,8 @@ def main():
     P = (min(a.taps, a.fft_size - 1024) + BLOCK - 1) // BLOCK
     shard_world = world if world > 1 else (a.emulate_world if a.force_sharded and a.emulate_world > 1 else 1)
     root_only = a.collective == "reduce"
-    n_distinct = 4  # rotate through a few distinct input batches
+    # rotate through a few distinct input batches (sharded runs feed every rank the GLOBAL batch, world x T blocks: two there)
+    n_distinct = 2 if sharded else 4
     comp = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(comp)
 

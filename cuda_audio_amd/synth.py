@@ -13,9 +13,12 @@ BLOCK = 256
 def make_input(n_frames, seed=1234, channels=2, dc=0.01, amp=0.25):
     """uniform(-amp, amp) + dc per channel, seed + channel; float32 [channels, n]."""
     out = np.empty((channels, n_frames), dtype=np.float32)
+    step = 1 << 24  # (drawn in pieces: the same stream as one draw, without a float64 copy of the whole channel)
     for ch in range(channels):
         rng = np.random.default_rng(seed + ch)
-        out[ch] = (rng.uniform(-amp, amp, n_frames) + dc).astype(np.float32)
+        for o in range(0, n_frames, step):
+            n = min(step, n_frames - o)
+            out[ch, o:o + n] = (rng.uniform(-amp, amp, n) + dc).astype(np.float32)
     return out
 
 
