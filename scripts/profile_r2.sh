@@ -10,7 +10,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$REPO/bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-latency --no-host-io --no-parity $@"
 echo "bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-latency --no-host-io --no-parity $@" > $OUT/command.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+# (the duration pass with the clocks warm, like the bench itself: 100 ms of untimed steps first; the counter passes without)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 ${ARGS/--prewarm-ms 0/--prewarm-ms 100} > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 pass() {  # name, counters
     rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -- python3 $ARGS > $OUT/$1.log 2>&1 || { echo "pass $1 failed"; tail -3 $OUT/$1.log; }
     # keep the merged output small: only the per-dispatch counter table

@@ -61,8 +61,8 @@ def main(tag, dominant, blocks=None):
             allc.setdefault(k, {}).update({n: mean(v) for n, v in cs.items()})
         for k, v in d.items():
             durs.setdefault(k, {})[p] = mean(v) / 1e3
-    lines = [f"# rocprofv3 summary - round 2, `{tag}`", "", f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 {cmd}`;",
-             "counters from separate `--kernel-trace --pmc ...` runs of the same command (scripts/profile_r2.sh), means per launch.", "",
+    lines = [f"# rocprofv3 summary - round 2, `{tag}`", "", f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 {cmd.replace('--prewarm-ms 0', '--prewarm-ms 100')}` (durations: 100 ms of untimed steps first, clocks warm as in the bench itself);",
+             "counters from separate `--kernel-trace --pmc ...` runs of the same command with `--prewarm-ms 0` (scripts/profile_r2.sh), means per launch.", "",
              "| kernel | calls | avg us | % of GPU time | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM-side MB (2 x fetch + write) |", "|---|---|---|---|---|---|---|"]
     traffic = {}
     for r in rows:
