@@ -2760,6 +2760,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_f2_prod(const float2* __restrict
 #ifndef G2_PF
 #define G2_PF 2  // groups of product entries whose spectra are loaded together
 #endif
+#ifndef G2_ABL
+#define G2_ABL 0  // timing-only ablations of k_g2_mac (wrong results), bit flags: 1 no global memory, 2 no butterflies, 4 no LDS accesses in the passes that load AND store (scripts/gpu_abl.sh)
+#endif
 #ifndef G2_AHEAD
 #define G2_AHEAD 0  // 1: the first G2_PF groups' spectra are requested before the forward transforms
 #endif
@@ -2781,6 +2784,9 @@ __device__ __forceinline__ void g2_tables(float2* t_lo, float2* t_hi) {  // w = 
 // the two radix-4 stages of a pass on a thread's 16 elements, in registers (a[m] = element pos0 + Q m)
 template <bool INV, int LQ>
 __device__ __forceinline__ void g2_pair_core(v2f (&a)[16], const float2* t_lo, const float2* t_hi, int j0) {
+#if G2_ABL & 2
+    return;
+#endif
     constexpr int step1 = G2_N >> (LQ + 4), step2 = G2_N >> (LQ + 2);
     const v2f wa = vg_tw(t_lo, t_hi, j0 * step1), w = vg_tw(t_lo, t_hi, j0 * step2);
     const v2f wr[4] = {wa, vx_mul(wa, W16_1), vx_mul(wa, W16_2), vx_mul(wa, W16_3)};
@@ -2819,6 +2825,16 @@ __device__ __forceinline__ void g2_pair(float2* s, const float2* t_lo, const flo
     // live across the whole kernel and spill
     asm volatile("" : "+v"(pos0), "+v"(j0));
     float2* p = s + G2_P(pos0);
+#if G2_ABL & 4
+    if (LOAD && STORE) {  // the butterflies on whatever the registers hold, kept alive without a store
+#pragma unroll
+        for (int m = 0; m < 16; m++) a[m] = v2f{__int_as_float(0x3f000000 | (pos0 + m)), __int_as_float(0x3f000000 | (j0 + m))};
+        g2_pair_core<INV, LQ>(a, t_lo, t_hi, j0);
+#pragma unroll
+        for (int m = 0; m < 16; m++) asm volatile("" ::"v"(a[m]));
+        return;
+    }
+#endif
     if (LOAD) {
 #pragma unroll
         for (int m = 0; m < 16; m++) a[m] = vx_ld(p + stride * m);
@@ -3148,6 +3164,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
 #if G2_STAMPS  // diagnostic build only: where a workgroup's time goes (s_memtime ticks = shader cycles)
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_now;
     int st_items = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #define G2_STAMP(k)                                                                       \
     do {                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
@@ -3188,7 +3205,11 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
                     for (int r = 0; r < G2B_FILL; r++) {
                         const int n = tt + G2B_THREADS * (r0 + r);
                         x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if G2_ABL & 1
+                        if (n < L) x[r] = make_float4(__int_as_float(0x3c000000 | n), 0.25f, -0.5f, __int_as_float(0x3c800000 | n));
+#else
                         if (n < L) x[r] = fk[(sb + n) & (ring - 1)];
+#endif
                     }
 #pragma unroll
                     for (int r = 0; r < G2B_FILL; r++) {
@@ -3240,8 +3261,13 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
                     const unsigned off = ((unsigned)tt + G2B_THREADS * (unsigned)r) * 16u;
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
+#if G2_ABL & 1
+                        HLq[r % RING][i] = make_float4(__int_as_float(0x3c000000 | off), 0.5f, 0.25f, __int_as_float(0x3c400000 | off));
+                        HRq[r % RING][i] = make_float4(0.5f, __int_as_float(0x3c000000 | off), __int_as_float(0x3c400000 | off), 0.25f);
+#else
                         HLq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + off);
                         HRq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + (size_t)257 * G2_N * sizeof(float2) + off);
+#endif
                     }
                 };
 #pragma unroll
@@ -3318,7 +3344,11 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
 #pragma unroll
                 for (int m = 0; m < ROWS; m++) {
                     const int t = tt + G2B_THREADS * m - (taps - 1);
+#if G2_ABL & 1
+                    if (t >= 0 && t < nout && ycap < 0) {
+#else
                     if (t >= 0 && t < nout) {
+#endif
                         float4 y = make_float4(yl[m].x * sc, yl[m].y * sc, yr[m].x * sc, yr[m].y * sc);  // (second run of bin 0: h2 * conj z)
                         if (pass) {
                             const float4 o = dst[t];
@@ -3336,8 +3366,257 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
         }
     }
 #if G2_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 137 || blockIdx.x == 300 || blockIdx.x == 700 || blockIdx.x == 1100)) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - st_t0, dr = __builtin_amdgcn_s_memrealtime() - st_r0;
+        printf("g2 wg %d: %llu cycles in %llu x 10 ns = %.0f MHz\n", (int)blockIdx.x, dt, dr, (double)dt / (double)dr * 100.0);
+    }
     if (threadIdx.x == 0 && (blockIdx.x == 3 || blockIdx.x == 137 || blockIdx.x == 300 || blockIdx.x == 700 || blockIdx.x == 1100))
         printf("g2 wg %d items %d: fill %llu fwd1 %llu x1regs+x2fill %llu fwd2 %llu products %llu inv1 %llu out1+yrfill %llu inv2 %llu store %llu\n",
                (int)blockIdx.x, st_items, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8]);
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// k_g2_duo: the fused second-level transform as ONE workgroup of 1024 threads per CU whose two halves ("groups") run
+// k_g2_mac's per-item sequence on a buffer each, ONE PHASE APART, in barrier lockstep (round 3).
+//
+// Why.  Measured on k_g2_mac (profiles/r3_g2_ablation.md): with its butterflies and LDS passes removed the launch still
+// takes 238 of 364 us - the memory phases alone - and with two independent workgroups per CU the transforms' time is
+// simply added on top: a workgroup that is alone in a memory phase does not fill the CU's memory pipe, two workgroups in
+// memory phases at once share it, and nothing makes the two alternate (a second co-resident workgroup buys 14 %, where
+// perfect alternation would buy ~50 %).  A CU pulls HBM-class data at the chip's rate / 256 whatever is in flight, so
+// the HBM side is only busy while EVERY CU has requests outstanding.
+// Here the alternation is built in.  An item is four phases of G2D_NB barriers each -
+//   F    window loads issued at once, four idle barriers, wait + unpack                      (memory: HBM read)
+//   C12  forward transforms of x1 and x2                                                     (VALU / LDS)
+//   P    products against the four paths' spectra, streamed one entry pair ahead             (memory: L2 read)
+//   C34  inverse transforms of Y_L and Y_R, the stores issued behind the last pass           (VALU / LDS; HBM write drains under F)
+// - every barrier is the whole workgroup's s_barrier, and group 1 starts one phase late: group 0's C12 runs beside
+// group 1's F, its P beside group 1's C12, its C34 beside group 1's P, its next F beside group 1's C34.  A memory
+// phase always has a compute phase of the other group beside it, by construction instead of by chance.  Barriers
+// inside a memory phase cost the waiting group nothing (loads and stores stay in flight across s_barrier: it is issued
+// bare, behind s_waitcnt lgkmcnt(0) only); a group without an item in a round, and the partner of a bin-0 item's second
+// run, execute the same number of barriers empty.
+// Persistent: grid = 8 k workgroups (<= CUs); the 2 * grid / 8 workers of an XCD lane (blockIdx & 7, speed only) walk
+// the lane's items in order - chunk after chunk of a bin, bin after bin - so that a bin's second-level spectra and the
+// overlap of adjacent windows are read into that XCD's L2 once, as in k_g2_mac.
+// Same arithmetic in the same order per item as k_g2_mac: bit-identical sums.
+// Bounds: as at k_g2_mac_wide (items via xq < nitems / 8, window slots masked into the ring, spectrum rows, t_c0 + t <
+// T <= ycap); LDS: G2_P(8191) < G2_LDS per group.
+// ---------------------------------------------------------------------------
+#define G2D_THREADS 1024
+#define G2D_NB 5
+__device__ __forceinline__ void g2d_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void g2d_bars(int n) {
+    for (int i = 0; i < n; i++) g2d_bar();
+}
+
+__global__ __launch_bounds__(G2D_THREADS, 4) void k_g2_duo(const float4* __restrict__ fdl, int ring, int slot0, int T, int chunk_t,
+                                                            int taps, Fft2Voices vv, float4* __restrict__ Yc, int ycap, int nitems,
+                                                            int nrounds, int solo) {
+    __shared__ float2 s2[2][G2_LDS];
+    __shared__ float2 t_lo[128], t_hi[64];
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));
+    float2* s = s2[grp];
+    const int nch = nitems >> 8, nxq = nitems >> 3;
+    g2_tables(t_lo, t_hi);
+    __syncthreads();
+    if (grp) g2d_bars(G2D_NB);  // group 1 runs one phase behind group 0
+    // solo (measurement, MCCONV_G2_DUO_SOLO=1): group 0 takes every item, group 1 only keeps the barriers company
+    const int lane8 = blockIdx.x & 7, wpl = (int)(gridDim.x >> 3) * (solo ? 1 : 2), jw = (int)(blockIdx.x >> 3) * (solo ? 1 : 2);
+#if G2_STAMPS
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0, st_now;
+    int st_items = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define G2D_STAMP(k)                                                                   \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((k) >= 0) st_acc[(k) < 0 ? 0 : (k)] += st_now - st_prev;                   \
+        st_prev = st_now;                                                              \
+    } while (0)
+#else
+#define G2D_STAMP(k) do { } while (0)
+#endif
+    constexpr int ROWS = G2_N / G2B_THREADS;                    // 16 window entries per thread and sequence
+    constexpr int PS = 2 * G2B_THREADS + 2 * G2B_THREADS / 32;  // ... of entry pairs 2 j, 2 (j + 512)
+    for (int rnd = 0; rnd < nrounds; rnd++) {
+        const int xq0 = rnd * wpl + jw, xq = xq0 + (solo ? 0 : grp);
+        const bool valid = xq < nxq && !(solo && grp);
+        // a bin-0 item runs twice (z against h1, conj z against h2): its partner keeps it company with empty barriers
+        const bool twice = lane8 == 0 && xq0 < nch;  // (xq0 < nch: group 0's item, and with it or without it group 1's, is bin 0's)
+        const int bin = (xq / nch) * 8 + lane8, chunk = xq % nch;
+        const int t_c0 = chunk * chunk_t, nout = min(chunk_t, T - t_c0), L = nout + taps - 1;
+        const float4* fk = fdl + (size_t)bin * ring;
+        const int sb = slot0 + t_c0 - (taps - 1);
+        for (int pass = 0; pass < (twice ? 2 : 1); pass++) {
+            if (!valid || (pass && bin != 0)) {
+                g2d_bars(4 * G2D_NB);
+                continue;
+            }
+            const float cj = pass ? -1.0f : 1.0f;  // second run of bin 0: conj(z)
+            const int row = pass ? 256 : bin;
+            int tt = threadIdx.x & (G2B_THREADS - 1);
+            asm volatile("" : "+v"(tt));
+            G2D_STAMP(-1);
+            // ---- F: the window (16 bytes per slot carry both inputs), all rows requested at once
+            v2f x1[ROWS], x2[ROWS];
+            {
+                float4 x[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int n = tt + G2B_THREADS * r;
+                    x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < L) x[r] = fk[(sb + n) & (ring - 1)];
+                }
+                g2d_bars(G2D_NB - 1);  // (the other group's inverse transforms run meanwhile)
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    x1[r] = v2f{x[r].x, cj * x[r].y};
+                    x2[r] = v2f{x[r].z, cj * x[r].w};
+                }
+            }
+            g2d_bar();
+            G2D_STAMP(0);
+            // ---- C12: forward transforms; the first pass on the registers just loaded (see k_g2_mac)
+            g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x1);  // quarter lengths 2048, 512
+            g2d_bar();
+            g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);  // 128, 32
+            G2B_WAVE_SYNC();
+            g2_pair<false, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);  // 8, 2
+            g2d_bar();
+            v2f X1[ROWS];
+            {
+                asm volatile("" : "+v"(tt));
+                const float2* pp = &s[G2_P(2 * tt)];
+#pragma unroll
+                for (int r = 0; r < ROWS / 2; r++) {
+                    const v2f a = vx_ld(pp + r * PS), b = vx_ld(pp + r * PS + 1);
+                    X1[2 * r] = a + b;
+                    X1[2 * r + 1] = a - b;
+                }
+            }
+            g2d_bar();  // every thread has its X1 entries: the buffer is free for x2
+            g2_pair<false, 9, false, true>(s, t_lo, t_hi, tt, tt, x2);
+            g2d_bar();
+            g2_pair<false, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+            G2B_WAVE_SYNC();
+            g2_pair<false, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
+            g2d_bar();
+            G2D_STAMP(1);
+            // ---- P: products (as in k_g2_mac); barriers after entry pairs 0, 3, 4, 5 and 7 pair its pieces with the other
+            // group's forward passes (short, long, the register hand-off, short, long)
+            {
+                asm volatile("" : "+v"(tt));
+                float2* pp = &s[G2_P(2 * tt)];
+                constexpr int NP = ROWS / 2, RING = G2B_AHEAD + 1;
+                float4 HLq[RING][2], HRq[RING][2];
+                const char* hrow[2] = {reinterpret_cast<const char*>(vv.h0[0] + (size_t)row * G2_N),
+                                       reinterpret_cast<const char*>(vv.h1[0] + (size_t)row * G2_N)};
+                auto request = [&](int r) {
+                    const unsigned off = ((unsigned)tt + G2B_THREADS * (unsigned)r) * 16u;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        HLq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + off);
+                        HRq[r % RING][i] = *reinterpret_cast<const float4*>(hrow[i] + (size_t)257 * G2_N * sizeof(float2) + off);
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < G2B_AHEAD; r++) request(r);
+#pragma unroll
+                for (int r = 0; r < NP; r++) {
+                    if (r + G2B_AHEAD < NP) request(r + G2B_AHEAD);
+                    const unsigned off = ((unsigned)tt + G2B_THREADS * (unsigned)r) * 16u;
+                    const v2f a = vx_ld(pp + r * PS), b = vx_ld(pp + r * PS + 1);
+                    const v2f S[2][2] = {{X1[2 * r], X1[2 * r + 1]}, {a + b, a - b}};
+                    v2f aL0 = v2f{0.f, 0.f}, aL1 = aL0, aR0 = aL0, aR1 = aL0;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+#pragma unroll
+                        for (int vi = 0; vi < MC_MAXV; vi++) {
+                            if (vi >= vv.n) break;
+                            const float gl = i == 0 ? vv.g[vi].x : vv.g[vi].y, gr = i == 0 ? vv.g[vi].z : vv.g[vi].w;
+                            float4 HL, HR;
+                            if (vi == 0) {
+                                HL = HLq[r % RING][i];
+                                HR = HRq[r % RING][i];
+                            } else {
+                                const char* hb = reinterpret_cast<const char*>((i == 0 ? vv.h0[vi] : vv.h1[vi]) + (size_t)row * G2_N);
+                                HL = *reinterpret_cast<const float4*>(hb + off);
+                                HR = *reinterpret_cast<const float4*>(hb + (size_t)257 * G2_N * sizeof(float2) + off);
+                            }
+                            aL0 += gl * vx_mul(S[i][0], v2f{HL.x, HL.y});
+                            aL1 += gl * vx_mul(S[i][1], v2f{HL.z, HL.w});
+                            aR0 += gr * vx_mul(S[i][0], v2f{HR.x, HR.y});
+                            aR1 += gr * vx_mul(S[i][1], v2f{HR.z, HR.w});
+                        }
+                    }
+                    vx_st(pp + r * PS, aL0 + aL1);  // the inverse transform's radix-2 stage on the way out
+                    vx_st(pp + r * PS + 1, aL0 - aL1);
+                    X1[2 * r] = aR0 + aR1;
+                    X1[2 * r + 1] = aR0 - aR1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r == 0 || r == 3 || r == 4 || r == 5 || r == NP - 1) g2d_bar();
+                }
+            }
+            G2D_STAMP(2);
+            // ---- C34: inverse transforms; the stores are issued behind the last pass and drain under the next phase
+            v2f yl[ROWS];
+            g2_pair<true, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
+            G2B_WAVE_SYNC();
+            g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+            g2d_bar();
+            g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yl);
+            g2d_bar();
+            {
+                asm volatile("" : "+v"(tt));
+                float2* pp = &s[G2_P(2 * tt)];
+#pragma unroll
+                for (int r = 0; r < ROWS / 2; r++) {
+                    vx_st(pp + r * PS, X1[2 * r]);
+                    vx_st(pp + r * PS + 1, X1[2 * r + 1]);
+                }
+            }
+            g2d_bar();
+            {
+                v2f yr[ROWS];
+                g2_pair<true, 1>(s, t_lo, t_hi, G2B_POS1(tt), (tt >> 5) & 1);
+                G2B_WAVE_SYNC();
+                g2_pair<true, 5>(s, t_lo, t_hi, ((tt >> 5) << 9) + (tt & 31), tt & 31);
+                g2d_bar();
+                g2_pair<true, 9, true, false>(s, t_lo, t_hi, tt, tt, yr);
+                asm volatile("" : "+v"(tt));
+                const float sc = 1.0f / (float)G2_N;
+                float4* dst = Yc + (size_t)bin * ycap + t_c0;
+#pragma unroll
+                for (int m = 0; m < ROWS; m++) {
+                    const int t = tt + G2B_THREADS * m - (taps - 1);
+                    if (t >= 0 && t < nout) {
+                        float4 y = make_float4(yl[m].x * sc, yl[m].y * sc, yr[m].x * sc, yr[m].y * sc);
+                        if (pass) {
+                            const float4 o = dst[t];
+                            y = make_float4(o.x + y.x, o.y + y.y, o.z + y.z, o.w + y.w);
+                        }
+                        dst[t] = y;
+                    }
+                }
+            }
+            g2d_bar();  // the buffer is free for the next run
+            G2D_STAMP(3);
+#if G2_STAMPS
+            st_items++;
+#endif
+        }
+    }
+    if (!grp) g2d_bars(G2D_NB);
+#if G2_STAMPS
+    if ((threadIdx.x & 511) == 0 && (blockIdx.x == 3 || blockIdx.x == 137 || blockIdx.x == 200))
+    {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - st_t0, dr = __builtin_amdgcn_s_memrealtime() - st_r0;
+        printf("g2 wg %d grp %d items %d: F %llu C12 %llu P %llu C34 %llu (cycles per item); workgroup %llu cycles in %llu x 10 ns = %.0f MHz\n",
+               (int)blockIdx.x, grp, st_items, st_acc[0] / st_items, st_acc[1] / st_items, st_acc[2] / st_items, st_acc[3] / st_items,
+               dt, dr, (double)dt / (double)dr * 100.0);
+    }
 #endif
 }

@@ -61,7 +61,8 @@ inline double pan_r(double p) { return p <= 0 ? 1 + p : 1; }  // conv.cu:387
 
 struct IrEntry {
     float4* d_H = nullptr;
-    float4* d_Hp[3] = {nullptr, nullptr, nullptr};  // fast-FIR components of the partition sequence: 3 / 9 / 27 arrays
+    float4* d_Hp[3] = {nullptr, nullptr, nullptr};  // fast-FIR components of the partition sequence: 3 / 9 / 27 arrays,
+    bool hp_valid[3] = {false, false, false};       // built on the first batch that selects that level (ensure_hp)
     float2* d_H2 = nullptr;  // second-level spectra [2 ch][257 rows][F2_N], built on first use (k_fft2_ir)
     bool h2_valid = false;
     float2* d_G2 = nullptr;  // second-level spectra for the fused 8192-point form [2 ch][257 rows][G2_N]
@@ -255,6 +256,8 @@ struct mc_engine {
     bool host_out_direct = true;  // MCCONV_HOST_OUT_DIRECT=0: pinned-buffer batches copy their output out instead of storing it to the host
     unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
     unsigned* hd_exited = nullptr;
+    // how often a parked period was used / gave up on its own (host away > park_ms) / was told to give up: mc_debug_read item 6
+    uint64_t n_park_hit = 0, n_park_timeout = 0, n_park_cancel = 0;
 #ifdef MC_JACK_TRACE
     double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0;
     unsigned long long tr_prev_end = 0;
@@ -275,6 +278,12 @@ struct mc_engine {
     unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
     unsigned* d_cflag = nullptr;    // [ceil(Tmax/256)] launch sequence number per published chunk total
     unsigned cticket_base = 0, cflag_seq = 0;
+    // k_g2_duo (round 3): one 1024-thread workgroup per CU whose halves run the items' phases in lockstep, one phase apart.
+    // Measured equal to k_g2_mac at 20 chunks per bin and slower below (profiles/r3_g2_ablation.md): NOT the default;
+    // MCCONV_G2_DUO=1 selects it for launches of at least _DUO_MINCH chunks per bin; _DUO_GRID: its workgroups (a multiple
+    // of 8, default = the CUs)
+    bool g2_duo = false;
+    int g2_duo_minch = 3, g2_duo_grid = 256;
     bool g2_wide = false;    // MCCONV_G2_WIDE=1: the one-workgroup-per-CU form of the kernel (1024 threads, both sequences in LDS)
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
@@ -328,6 +337,7 @@ void unpark(mc_engine* e) {
     if (e->pre.valid) {
         ring_bell(e, e->pre.seq, 1);
         e->pre.valid = false;
+        e->n_park_cancel++;
     }
 }
 int leave_jack_path(mc_engine* e) {
@@ -430,17 +440,26 @@ int zero_state(mc_engine* e) {
 
 int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 
-// fast-FIR components of an IR's spectra (levels 1 and 2) for the resident MAC
-int build_polyphase(mc_engine* e, IrEntry& ir) {
-    ir.h2_valid = ir.g2_valid = false;  // the spectra changed: the second-level spectra are rebuilt on next use
-    if (e->half || e->Pstride < 128) return MC_OK;  // the fp16 MAC streams; small engines never use the fast form
-    for (int lvl = 1; lvl <= 3; lvl++) {
-        if ((e->Pstride >> lvl) < 32) break;
-        const size_t n = (size_t)(lvl == 1 ? 3 : (lvl == 2 ? 9 : 27)) * MC_NB * (e->Pstride >> lvl);
-        if (!ir.d_Hp[lvl - 1]) HIP_TRY(hipMalloc(&ir.d_Hp[lvl - 1], sizeof(float4) * n));
-        hipLaunchKernelGGL(k_polyphase, dim3(2048), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp[lvl - 1], e->Pstride, lvl);
-    }
+// An IR's spectra changed (load, reload, mix): everything derived from them - the second-level spectra and the fast-FIR
+// components - is rebuilt on next use.  (Round 2 built the fast-FIR components eagerly at every load: 60 MB and three
+// launches per 10 s IR for a form that only MCCONV_FFT2=0 selects.)
+void invalidate_derived(IrEntry& ir) {
+    ir.h2_valid = ir.g2_valid = false;
+    ir.hp_valid[0] = ir.hp_valid[1] = ir.hp_valid[2] = false;
+}
+// whether the fast-FIR form of level lvl (1..3) exists for this engine at all
+bool hp_possible(const mc_engine* e, int lvl) {
+    return !e->half && e->Pstride >= 128 && (e->Pstride >> lvl) >= 32;  // the fp16 MAC streams; small engines never use the fast form
+}
+// fast-FIR components of an IR's spectra (level lvl) for the resident MAC, built on first use
+int ensure_hp(mc_engine* e, const IrEntry* irc, int lvl) {
+    IrEntry& ir = *const_cast<IrEntry*>(irc);
+    if (ir.hp_valid[lvl - 1]) return MC_OK;
+    const size_t n = (size_t)(lvl == 1 ? 3 : (lvl == 2 ? 9 : 27)) * MC_NB * (e->Pstride >> lvl);
+    if (!ir.d_Hp[lvl - 1]) HIP_TRY(hipMalloc(&ir.d_Hp[lvl - 1], sizeof(float4) * n));
+    hipLaunchKernelGGL(k_polyphase, dim3(2048), dim3(256), 0, e->stream, ir.d_H, ir.d_Hp[lvl - 1], e->Pstride, lvl);
     HIP_TRY(hipGetLastError());
+    ir.hp_valid[lvl - 1] = true;
     return MC_OK;
 }
 
@@ -507,8 +526,7 @@ int consolidate_voices(mc_engine* e, int i) {
     hipLaunchKernelGGL(k_mix, dim3(2048), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_H), nH, sH);
     hipLaunchKernelGGL(k_mix, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_h), (size_t)taps * 2, sh);
     HIP_TRY(hipGetLastError());
-    rc = build_polyphase(e, M);
-    if (rc) return rc;
+    invalidate_derived(M);
     std::memcpy(M.sums, sums, sizeof(sums));
     M.taps = taps;
     M.P = P;
@@ -955,7 +973,15 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                         fprintf(stderr, "  G2[%d] in1 [%p, %p) in2 [%p, %p)\n", a, (void*)vv.h0[a], (void*)(vv.h0[a] + (size_t)2 * 257 * G2_N),
                                 (void*)vv.h1[a], (void*)(vv.h1[a] + (size_t)2 * 257 * G2_N));
                 }
-                if (e->g2_wide)  // the one-workgroup-per-CU form (MCCONV_G2_WIDE=1)
+                if (e->g2_duo && !e->g2_wide && nch >= e->g2_duo_minch && e->g2_grid == (1 << 30)) {
+                    // the lockstep form: persistent, two workers (the halves of a workgroup) per CU; the Q1/Q2 terms do not ride
+                    // along (a rider would need a CU of its own: the launches of their own follow, as for every long batch)
+                    const int grid = std::max(8, std::min(e->g2_duo_grid, 256) & ~7);
+                    static const int solo = std::getenv("MCCONV_G2_DUO_SOLO") ? std::atoi(std::getenv("MCCONV_G2_DUO_SOLO")) : 0;  // (measurement: one group works alone)
+                    const int wpl = (grid >> 3) * (solo ? 1 : 2), nxq = (MC_NB * nch) >> 3;
+                    hipLaunchKernelGGL(k_g2_duo, dim3(grid), dim3(G2D_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax, vv,
+                                       e->d_Yc, e->Tcap, MC_NB * nch, (nxq + wpl - 1) / wpl, solo);
+                } else if (e->g2_wide)  // the one-workgroup-per-CU form (MCCONV_G2_WIDE=1)
                     hipLaunchKernelGGL(k_g2_mac_wide, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl,
                                        e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
                 else {
@@ -966,7 +992,8 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                         mo->corr_done = true;
                     }
                     const int main_grid = std::min(MC_NB * nch, e->g2_grid);
-                    hipLaunchKernelGGL(k_g2_mac, dim3(main_grid + ca.nchunks), dim3(G2B_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T,
+                    static const int dyn_lds = std::getenv("MCCONV_G2_DYNLDS") ? std::atoi(std::getenv("MCCONV_G2_DYNLDS")) : 0;  // (measurement: extra LDS per workgroup, > 22 KB leaves one workgroup per CU)
+                    hipLaunchKernelGGL(k_g2_mac, dim3(main_grid + ca.nchunks), dim3(G2B_THREADS), dyn_lds, e->stream, e->d_fdl, e->ring, slot0, T,
                                        chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch, ca, main_grid);
                 }
                 mo->ysrc = e->d_Yc;
@@ -1010,21 +1037,19 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
     int lvl = 0;
     if (mo->resident && e->ffa_levels > 0 && e->cfg.part_begin == 0 && e->cfg.part_end == 0 && nact > 0) {
         int pmin = 1 << 30;
-        bool have = true;
-        for (int a = 0; a < nact; a++) {
-            pmin = std::min(pmin, act[a].p_end);
-            have = have && act[a].ir0->d_Hp[0] && act[a].ir1->d_Hp[0];
-        }
-        auto ready = [&](int l) {
-            for (int a = 0; a < nact; a++)
-                if (!act[a].ir0->d_Hp[l - 1] || !act[a].ir1->d_Hp[l - 1]) return false;
-            return true;
-        };
+        const bool have = hp_possible(e, 1);
+        for (int a = 0; a < nact; a++) pmin = std::min(pmin, act[a].p_end);
+        auto ready = [&](int l) { return hp_possible(e, l); };
         if (have && e->ffa_levels >= 3 && T >= 8192 && T % 8 == 0 && pmin >= 1024 && ready(3)) lvl = 3;
         else if (have && e->ffa_levels >= 2 && T >= 4096 && T % 4 == 0 && pmin >= 512 && ready(2)) lvl = 2;
         else if (have && T >= 2048 && T % 2 == 0 && pmin >= 256) lvl = 1;
     }
     if (lvl) {
+        for (int a = 0; a < nact; a++) {  // the components of this level, built on the first batch that takes it
+            int rc = ensure_hp(e, act[a].ir0, lvl);
+            if (!rc) rc = ensure_hp(e, act[a].ir1, lvl);
+            if (rc) return rc;
+        }
         const int S = 1 << lvl, ncomp = lvl == 1 ? 3 : (lvl == 2 ? 9 : 27);
         const int nh = T / S, ph = e->Pstride >> lvl;
         const int tiles = (nh + 255) / 256;
@@ -1771,6 +1796,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         my_seq = e->pre.seq;
         ring_bell(e, my_seq, 0);
         e->pre.valid = false;
+        e->n_park_hit++;
         st_now = e->pre.st;
         pl_now = Plan();
         make_plan(st_now, pl_now);
@@ -1811,8 +1837,8 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     // slot carries its own gains, so it stays exact under any parameter change except a change of the sounding IR set
     // or an IR reload, which the next call checks)
     bool parked_next = false;
-    if (e->park && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half && params_steady(e, cc) &&
-        cc[0].predelay == e->cur_delay) {
+    if (e->park && e->stream == e->own_stream && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half &&
+        params_steady(e, cc) && cc[0].predelay == e->cur_delay) {
         Staged st_next;
         int rc = stage_params(e, 1, cc, &st_next);  // (steady: advancing the cross-fade by a block changes nothing)
         if (rc) return rc;
@@ -1896,7 +1922,16 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         // ordinary way behind whatever is queued
         if (!relaunch_ok) return fail(MC_ERR_HIP, "period did not complete");
         relaunch_ok = false;
+        e->n_park_timeout++;
         unpark(e);  // (the kernel parked for the period after this one must not run before it)
+        // That kernel (launched above, behind a tail that had already left the stream) ran at once: the sweep it carries - the
+        // one of the period after next - went into the partial-sum buffer of THIS period (same parity) and read a delay line
+        // without this period's block.  unpark() has forgotten it; this period's own partial sums are summed again, on the
+        // same stream behind the stray sweep.
+        {
+            int rc2 = launch_sweep(pl_now, e->t_front - 1);
+            if (rc2) return rc2;
+        }
         my_seq = ++e->flag_seq;
         hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front - 1, my_seq, false));
         HIP_TRY(hipGetLastError());
@@ -2189,6 +2224,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         my_seq = e->pre.seq;
         ring_bell(e, my_seq, 0);
         e->pre.valid = false;
+        e->n_park_hit++;
         st = e->pre.st;
         make_pplan(st, pl);
         relaunch_ok = true;
@@ -2222,8 +2258,8 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         if (rc) return rc;
         remember_sweep(pl, st, e->t_front);
     }
-    if (e->park && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half && params_steady(e, cc) &&
-        cc[0].predelay == e->cur_delay) {
+    if (e->park && e->stream == e->own_stream && e->speculate && e->spin_wait && !e->pipelined && !e->ktiming && !e->half &&
+        params_steady(e, cc) && cc[0].predelay == e->cur_delay) {
         Staged st_next;
         int rc = stage_params(e, pm, cc, &st_next);  // (steady: advancing the cross-fade by a call changes nothing)
         if (rc) return rc;
@@ -2257,6 +2293,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         // give up, its sweep is forgotten, and this period's own partial sums are summed again (the sweep behind overwrote them)
         if (!relaunch_ok) return fail(MC_ERR_HIP, "period did not complete");
         relaunch_ok = false;
+        e->n_park_timeout++;
         unpark(e);
         e->spec_valid = false;
         rc = sweep_or_zero(pl, e->t_front - (uint64_t)pm);
@@ -2501,6 +2538,13 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     // (any grid >= 1 is correct: a workgroup strides over the items; multiples of 8 keep a bin's chunks on one XCD)
     if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
+    if (const char* gd = std::getenv("MCCONV_G2_DUO")) e->g2_duo = std::atoi(gd) != 0;
+    if (const char* gd = std::getenv("MCCONV_G2_DUO_MINCH")) e->g2_duo_minch = std::max(1, std::atoi(gd));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) e->g2_duo_grid = std::min(cus & ~7, 256);
+    }
+    if (const char* gd = std::getenv("MCCONV_G2_DUO_GRID")) e->g2_duo_grid = std::max(8, std::atoi(gd));
     if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
     if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
     if (const char* tm = std::getenv("MCCONV_FFT2_WORK")) e->fft2_work = std::max<int64_t>(1, std::atoll(tm));
@@ -2668,11 +2712,12 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     }
     if (ir.d_h) (void)hipFree(ir.d_h);
     ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
-    {
-        int rc = build_polyphase(e, ir);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(e->stream));
-    }
+    invalidate_derived(ir);
+    for (int l = 0; l < 3; l++)  // (a reloaded IR gives its fast-FIR components back; the stream is idle here)
+        if (ir.d_Hp[l]) {
+            (void)hipFree(ir.d_Hp[l]);
+            ir.d_Hp[l] = nullptr;
+        }
     if (e->half) {
         // scaled fp16 copy: one power-of-two scale per IR puts the largest bin near 2^13 (half max 65504);
         // a 60 dB decay then still sits ~2^3 above the smallest normal half
@@ -2977,6 +3022,12 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         dims[3] = (uint64_t)e->wr;
     }
     if (!dst || !bytes) return MC_OK;
+    if (which == 6) {  // host-side counters of the JACK path's parked periods {used, gave up on their own, told to give up}: no stream access
+        const uint64_t c[3] = {e->n_park_hit, e->n_park_timeout, e->n_park_cancel};
+        if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
+        std::memcpy(dst, reinterpret_cast<const char*>(c) + off, bytes);
+        return MC_OK;
+    }
     const char* src = nullptr;
     uint64_t cap = 0;
     switch (which) {

@@ -162,6 +162,10 @@ class Convolution:
             raise ValueError("inputs must have equal length, a multiple of 256")
         if out is None:
             out = np.empty((2, n), np.float32)
+        elif (not isinstance(out, np.ndarray) or out.dtype != np.float32 or out.shape != (2, n)
+              or not out[0].flags.c_contiguous or not out[1].flags.c_contiguous or not out.flags.writeable):
+            # the library writes n float32 values through each row pointer: anything else would be written past or across
+            raise ValueError("out must be a writeable float32 array of shape (2, n) with C-contiguous rows")
         check(self._L.mc_process_batch(self._h, _fp(in1), _fp(in2), _fp(out[0]), _fp(out[1]), n // MC_BLOCK))
         return out
 
@@ -245,6 +249,13 @@ class Convolution:
 
     def blocks_processed(self):
         return self._L.mc_blocks_processed(self._h)
+
+    def park_stats(self):
+        """JACK path: how many parked periods were used, gave up on their own (host away longer than the park time)
+        and were told to give up (mc_debug_read item 6; host-side counters, no stream access)."""
+        a = np.zeros(3, np.uint64)
+        check(self._L.mc_debug_read(self._h, 6, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return dict(used=int(a[0]), timed_out=int(a[1]), cancelled=int(a[2]))
 
     def debug_dims(self):
         d = (C.c_uint64 * 4)()

@@ -1554,7 +1554,8 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor of the items, exactly the items,
     more than the items - gives the same bits; T is not a multiple of the chunk (6465 blocks) or of anything else, so
     the last chunk is ragged (MCCONV_G2_GRID; bounds argument at the kernel).  The same for the
-    one-workgroup-per-CU form with its look-ahead into the next item (MCCONV_G2_WIDE=1)."""
+    one-workgroup-per-CU form with its look-ahead into the next item (MCCONV_G2_WIDE=1) and for the lockstep form of
+    round 3 (k_g2_duo, MCCONV_G2_DUO=1)."""
     import torch
 
     from cuda_audio_amd.synth import make_input, make_ir
@@ -1564,10 +1565,13 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     T0, T = 2000, 9001  # settle the cross-fade with a first batch, then 6465 + 2536 blocks = 512 items
     x = torch.from_numpy(make_input((T0 + T) * 256)).to(dev)
 
-    def run(grid, wide=False):
+    def run(grid, wide=False, duo=None):
         monkeypatch.setenv("MCCONV_FFT2", "1")  # (the suite is also run with the measurement switches set)
         monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
         monkeypatch.setenv("MCCONV_G2_WIDE", "1" if wide else "0")
+        monkeypatch.setenv("MCCONV_G2_DUO", "0" if duo is None else "1")
+        monkeypatch.setenv("MCCONV_G2_DUO_MINCH", "1")
+        monkeypatch.setenv("MCCONV_G2_DUO_GRID", str(duo or 256))
         if grid is None:
             monkeypatch.delenv("MCCONV_G2_GRID", raising=False)
         else:
@@ -1597,6 +1601,12 @@ def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     for grid in (1, 7, 255, 513):
         got = run(grid, wide=True)
         assert np.array_equal(got, wide), f"MCCONV_G2_WIDE=1 MCCONV_G2_GRID={grid}: rms {rms(got - wide):.3e}"
+    # k_g2_duo (MCCONV_G2_DUO=1: the two halves of a 1024-thread workgroup run the items' phases one phase apart, in
+    # barrier lockstep): the same arithmetic per item, so the same bits - with two chunks per bin (both halves busy, the
+    # ragged chunk on the second), and with fewer workgroups than CUs (several rounds, a half without an item at the end)
+    for dgrid in (256, 8, 72, 200):
+        got = run(None, duo=dgrid)
+        assert np.array_equal(got, want), f"MCCONV_G2_DUO=1 MCCONV_G2_DUO_GRID={dgrid}: rms {rms(got - want):.3e}"
 
 
 def test_pinned_host_batches_overlap_copies_and_match(oracle_mod, gpu_lib):
@@ -1735,18 +1745,24 @@ def test_q4_output_clamp_parts_from_the_reference_only_after_saturation(oracle_m
 
 @pytest.mark.parametrize("period", [256, 512, 1024])
 def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib, monkeypatch, period):
-    """The JACK path launches the next period one call ahead and parks it on a doorbell (process_one; for 512- and
-    1024-frame periods process_period_fused, behind the period's sweep).  A host that pauses longer than the park time
-    (here 20 ms) finds that the parked tail gave up and launches the period again; controller changes, a batch call, an
-    IR reload and a reset in between tell the parked period to give up; the samples are the oracle's throughout.
-    MCCONV_NO_PARK=1 (every period launched on arrival) gives the same bits."""
+    """JACK path with periods launched one call ahead (process_one / process_period_fused): a period is parked only once
+    the cross-fade has converged EXACTLY (params_steady: coefficient == wet; the recurrence coef += (wet - coef) / 5 needs
+    ~160 calls from a cold start or a controller change), so the stream first settles for 180 calls and the test asserts
+    that periods WERE parked (mc_debug_read item 6).  Then: a host that pauses longer than the park time (here 20 ms)
+    finds that the parked tail gave up on its own and launches the period again - the kernel queued behind it has
+    meanwhile swept into this period's partial sums, which are summed again (round-2 advice: process_one did not);
+    a controller change, a batch call and an IR reload tell the parked period to give up; the samples are the oracle's
+    throughout.  MCCONV_NO_PARK=1 (every period launched on arrival) gives the same bits."""
     import time
 
     from cuda_audio_amd.synth import make_input, make_ir
 
-    n_ref, ncalls = 8192, 120
+    n_ref = 8192
+    settle = 180
     batch = 8 * 256  # frames of the batch call in between
-    total = (ncalls - 0) * period + batch
+    plan = (settle, 10, 10, settle, 5, 12, 10)
+    ncalls = sum(plan)
+    total = ncalls * period + batch
     x = make_input(total, seed=31)
     irs = [make_ir(6000, seed=61, norm=0.05), make_ir(5000, seed=63, norm=0.05)]
     p0, p1 = dict(BASE, select=0, wet=0.6), dict(BASE, select=1, level=0.9)
@@ -1755,6 +1771,7 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
         ref.prepare(i, ir)
     apply_params(ref, p0, p1, True)
     want = np.zeros((2, total))
+    stats = {}
 
     def stream(c, with_pauses):
         got = np.zeros((2, total), np.float32)
@@ -1767,27 +1784,35 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
                 got[:, s] = np.stack(c.onProcess(x[0, s], x[1, s]))
                 pos += period
 
-        periods(40)                      # the cold-start ramp converges: periods start to be parked
+        periods(plan[0])                 # the cold-start ramp converges exactly: periods are parked from ~call 160 on
+        stats["settled"] = c.park_stats()
         if with_pauses:
             time.sleep(0.06)             # longer than the park time: the parked tail gives up on its own
-        periods(10)
+        periods(plan[1])                 # (the first of them finds the exited tail and launches the period again)
+        stats["paused"] = c.park_stats()
         c.cc[0].value.wet = 0.3          # a controller moves: the parked period was staged with the old value
-        periods(10)
+        periods(plan[2])
         s = slice(pos, pos + batch)
         got[:, s] = c.process(x[0, s], x[1, s])  # a batch call in between (max_batch 8)
         pos += batch
-        periods(20)
-        c.prepare(1, irs[1])             # an IR reload (same taps): the parked tail had its spectra loaded already
-        periods(12)
+        periods(plan[3])                 # the cross-fade towards wet = 0.3 converges: parked again
+        stats["resettled"] = c.park_stats()
         if with_pauses:
             time.sleep(0.06)
-        periods(ncalls - 92)
+        periods(plan[4])
+        c.prepare(1, irs[1])             # an IR reload (same taps): the parked tail had its spectra loaded already
+        periods(plan[5])
+        if with_pauses:
+            time.sleep(0.06)
+        periods(plan[6])
+        stats["end"] = c.park_stats()
         assert pos == total
         return got
 
     # the oracle sees the same events at the same periods
     o = 0
-    for n, ev in ((50 * period, None), (total - 50 * period, "wet")):
+    first = (plan[0] + plan[1]) * period
+    for n, ev in ((first, None), (total - first, "wet")):
         if ev == "wet":
             ref.set(0, wet=0.3)
         s = slice(o, o + n)
@@ -1806,6 +1831,16 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
         apply_params(c, p0, p1, False)
         outs.append(stream(c, with_pauses=park))
         c.close()
+        if park:
+            # the paths under test really ran: parked periods were used before the first pause, a pause made one time out,
+            # the controller / batch / reload told parked periods to give up, and parking resumed after the second settling
+            assert stats["settled"]["used"] >= 5, stats
+            assert stats["paused"]["timed_out"] >= 1, stats
+            assert stats["resettled"]["used"] > stats["paused"]["used"] + 5, stats
+            assert stats["resettled"]["cancelled"] >= 1, stats
+            assert stats["end"]["timed_out"] >= 3, stats
+        else:
+            assert stats["end"] == dict(used=0, timed_out=0, cancelled=0), stats
         err = rms(outs[-1] - want)
         assert err <= RMS_TOL, f"park={park}: rms {err:.3e}"
     assert np.array_equal(outs[0], outs[1])
