@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/mcconv.h"
+#include "params_handoff.h"
 #include "kernels.hip.h"
 #include "singlefft.hip.h"
 
@@ -208,9 +209,10 @@ struct mc_engine {
     bool ptab_ev_used[kStageBufs] = {false, false, false, false};
     int ptab_next = 0;
 
-    // parameters: written by any thread, sampled at the start of a process call
-    std::mutex pmu;
-    mc_cc_value cc[2];
+    // parameters: written by any thread (mc_set_params, mc_handle_cc), sampled at the start of a process call without a
+    // lock (params_handoff.h); last_gen = the generation of the pair the last process call ran on (mc_debug_read item 7)
+    ParamHandoff ph;
+    uint64_t last_gen = 0;
 
     // Cross-fade state.  The reference keeps live spectra irFFT_i and pulls them towards
     // wet_i * H_sel_i every block: irFFT += (wet H_sel - irFFT)/(vsteps+5) (conv.cu:27, 339-353).
@@ -666,11 +668,7 @@ const IrEntry* any_ir(const mc_engine* e) {
 
 // cc[i].value as the call sees it (conv.cu reads the public fields once per onProcess)
 int sample_params(mc_engine* e, mc_cc_value (&cc)[2]) {
-    {
-        std::lock_guard<std::mutex> lk(e->pmu);
-        cc[0] = e->cc[0];
-        cc[1] = e->cc[1];
-    }
+    e->last_gen = e->ph.sample(cc);
     for (int i = 0; i < 2; i++) {
         if (cc[i].select >= (uint64_t)kMaxIrs || !e->irs[cc[i].select].d_H)
             return fail(MC_ERR_STATE, "half %d selects IR %llu which is not loaded", i, (unsigned long long)cc[i].select);
@@ -721,15 +719,15 @@ int stage_params(mc_engine* e, int T, mc_cc_value (&cc)[2], Staged* st) {
     // reuse of a pinned staging buffer: wait until its previous upload has run
     if (e->ptab_ev_used[e->ptab_next]) HIP_TRY(hipEventSynchronize(e->ptab_ev[e->ptab_next]));
     int berr = MC_OK;
+    const uint64_t sampled_vsteps[2] = {cc[0].vsteps, cc[1].vsteps};  // (build_params counts its copy down as it goes)
     const int pstride = build_params(e, T, cc, &tab, &ntab, &berr);
     if (berr) return berr;
-    {
-        // vsteps counts down on the engine's copy too (conv.cu:345,353)
-        std::lock_guard<std::mutex> lk(e->pmu);
-        for (int i = 0; i < 2; i++) {
-            uint64_t used = std::min<uint64_t>(e->cc[i].vsteps, (uint64_t)(T / e->pm));
-            e->cc[i].vsteps -= used;
-        }
+    for (int i = 0; i < 2; i++) {
+        // vsteps counts down on the engine's copy too (conv.cu:345,353): a compare-exchange against the value this call
+        // sampled, so that a select which arrived meanwhile (vsteps = speed, conv.cu:261) is not undone
+        const uint64_t used = std::min<uint64_t>(sampled_vsteps[i], (uint64_t)(T / e->pm));
+        e->ph.count_down(i, sampled_vsteps[i], used);
+        cc[i].vsteps = sampled_vsteps[i] - used;  // (a second staging in the same call - the period parked ahead - goes on from here)
     }
     bool need_upload = true;
     if (pstride == 0 && e->uniform_valid[bslot] && std::memcmp(&e->uniform_bp[bslot], &tab[0], sizeof(BlockParams)) == 0)
@@ -2359,8 +2357,10 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (!e) return fail(MC_ERR_NOMEM, "out of host memory");
     e->cfg = *cfg;
     e->device = dev;
-    mc_default_params(&e->cc[0]);
-    mc_default_params(&e->cc[1]);
+    e->ph.update([](mc_cc_value (&cc)[2]) {
+        mc_default_params(&cc[0]);
+        mc_default_params(&cc[1]);
+    });
     std::memset(&e->ks, 0, sizeof(e->ks));
     e->Tmax = (int)cfg->max_batch;
     e->Tcap = std::max(e->Tmax, 256);
@@ -2763,39 +2763,39 @@ int mc_ir_info(const mc_engine* e, uint64_t idx, double out[6]) {
 
 int mc_set_params(mc_engine* e, int half, const mc_cc_value* v) {
     if (!e || !v || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(e->pmu);
-    e->cc[half] = *v;
+    e->ph.update([&](mc_cc_value (&cc)[2]) { cc[half] = *v; });
     return MC_OK;
 }
 
 int mc_get_params(const mc_engine* e, int half, mc_cc_value* v) {
     if (!e || !v || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
-    mc_engine* m = const_cast<mc_engine*>(e);
-    std::lock_guard<std::mutex> lk(m->pmu);
-    *v = m->cc[half];
+    mc_cc_value cc[2];
+    e->ph.sample(cc);
+    *v = cc[half];
     return MC_OK;
 }
 
 int mc_handle_cc(mc_engine* e, int half, const uint8_t ccmap[8], uint8_t m2, int val) {
     // handleCC, conv.cu:255-276
     if (!e || !ccmap || half < 0 || half > 1) return fail(MC_ERR_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(e->pmu);
-    mc_cc_value& v = e->cc[half];
     const uint64_t nb = (uint64_t)e->nirs;
-    if (ccmap[0] == m2) {
-        v.select = (uint64_t)val * nb / 0x80;
-        v.vsteps = v.speed;
-    }
-    if (ccmap[1] == m2) v.predelay = (uint64_t)val * MC_MAX_PREDELAY / 0x80;
-    if (ccmap[2] == m2) v.dry = val / 128.0f;
-    if (ccmap[3] == m2) v.wet = val / 128.0f;
-    if (ccmap[5] == m2) v.panDry = val / 64.0f - 1;
-    if (ccmap[6] == m2) v.panWet = val / 64.0f - 1;
-    if (ccmap[7] == m2) v.level = val / 128.0f;
-    if (ccmap[4] == m2) {
-        v.speed = ((uint64_t)val * MC_MAX_SPEED) / 0x80;
-        if (v.vsteps > v.speed) v.vsteps = v.speed;
-    }
+    e->ph.update([&](mc_cc_value (&cc)[2]) {
+        mc_cc_value& v = cc[half];
+        if (ccmap[0] == m2) {
+            v.select = (uint64_t)val * nb / 0x80;
+            v.vsteps = v.speed;
+        }
+        if (ccmap[1] == m2) v.predelay = (uint64_t)val * MC_MAX_PREDELAY / 0x80;
+        if (ccmap[2] == m2) v.dry = val / 128.0f;
+        if (ccmap[3] == m2) v.wet = val / 128.0f;
+        if (ccmap[5] == m2) v.panDry = val / 64.0f - 1;
+        if (ccmap[6] == m2) v.panWet = val / 64.0f - 1;
+        if (ccmap[7] == m2) v.level = val / 128.0f;
+        if (ccmap[4] == m2) {
+            v.speed = ((uint64_t)val * MC_MAX_SPEED) / 0x80;
+            if (v.vsteps > v.speed) v.vsteps = v.speed;
+        }
+    });
     return MC_OK;
 }
 
@@ -2964,10 +2964,10 @@ uint64_t mc_algorithmic_bytes_per_block(const mc_engine* e) {
     // 4 IR paths + 2 delay-line inputs, P partitions, 256 bins x 8 B
     if (!e) return 0;
     if (e->sf) return 24ull * e->cfg.n_ref;  // four half spectra (4 N/2 x 8 B) + the input window (2 N x 4 B), per call
-    mc_engine* m = const_cast<mc_engine*>(e);
-    std::lock_guard<std::mutex> lk(m->pmu);
-    const IrEntry& a = e->irs[e->cc[0].select % kMaxIrs];
-    const IrEntry& b = e->irs[e->cc[1].select % kMaxIrs];
+    mc_cc_value cc[2];
+    e->ph.sample(cc);
+    const IrEntry& a = e->irs[cc[0].select % kMaxIrs];
+    const IrEntry& b = e->irs[cc[1].select % kMaxIrs];
     int P = std::max(a.P, b.P);
     if (e->cfg.part_end) P = std::max(0, std::min<int>(P, (int)e->cfg.part_end) - (int)e->cfg.part_begin);
     return (uint64_t)(4 + 2) * (uint64_t)P * MC_NB * (e->half ? 4ull : 8ull);
@@ -2977,8 +2977,6 @@ uint64_t mc_blocks_processed(const mc_engine* e) { return e ? e->t_abs : 0; }
 
 uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
     if (!e) return 0;
-    mc_engine* m = const_cast<mc_engine*>(e);
-    std::lock_guard<std::mutex> lk(m->pmu);
     at_most = std::min<uint64_t>(at_most, (uint64_t)e->Tmax);
     if (e->sf) return at_most - at_most % (uint64_t)e->pm;
     int pmax = 0;
@@ -3022,6 +3020,13 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         dims[3] = (uint64_t)e->wr;
     }
     if (!dst || !bytes) return MC_OK;
+    if (which == 7 || which == 8) {  // generation of the parameter pair the last process call sampled (7) / published last (8): no stream access
+        mc_cc_value cc[2];
+        const uint64_t g = which == 7 ? e->last_gen : e->ph.sample(cc);
+        if (off + bytes > sizeof(uint64_t)) return fail(MC_ERR_ARG, "read beyond the generation word");
+        std::memcpy(dst, reinterpret_cast<const char*>(&g) + off, bytes);
+        return MC_OK;
+    }
     if (which == 6) {  // host-side counters of the JACK path's parked periods {used, gave up on their own, told to give up}: no stream access
         const uint64_t c[3] = {e->n_park_hit, e->n_park_timeout, e->n_park_cancel};
         if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");

@@ -85,17 +85,12 @@ inline int sf_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t fram
 }
 
 // One call of the reference's onProcess on buffers the device can read and write.  The parameters are sampled and the
-// cross-fade counters stepped under the lock, as onProcess does with its public members (conv.cu:339-353).
+// cross-fade counters stepped (compare-exchange, no lock), as onProcess does with its public members (conv.cu:339-353).
 inline int sf_call(mc_engine* e, const float* in1, const float* in2, float* outL, float* outR, int nframes, bool publish = false) {
     SfState* s = e->sf;
     mc_cc_value cc[2];
-    {
-        std::lock_guard<std::mutex> lk(e->pmu);
-        cc[0] = e->cc[0];
-        cc[1] = e->cc[1];
-        for (int i = 0; i < 2; i++)
-            if (e->cc[i].vsteps > 0) e->cc[i].vsteps--;
-    }
+    e->last_gen = e->ph.sample(cc);  // (lock-free: params_handoff.h)
+    for (int i = 0; i < 2; i++) e->ph.count_down(i, cc[i].vsteps, cc[i].vsteps > 0 ? 1 : 0);
     for (int i = 0; i < 2; i++)
         if (cc[i].select >= (uint64_t)kMaxIrs || !e->irs[cc[i].select].d_S)
             return fail(MC_ERR_STATE, "half %d selects IR %llu which is not loaded", i, (unsigned long long)cc[i].select);

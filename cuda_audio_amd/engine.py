@@ -257,6 +257,13 @@ class Convolution:
         check(self._L.mc_debug_read(self._h, 6, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
         return dict(used=int(a[0]), timed_out=int(a[1]), cancelled=int(a[2]))
 
+    def param_generation(self, published=False):
+        """Generation number of the parameter pair the last process call ran on (published=True: of the pair
+        published last).  Every mc_set_params / mc_handle_cc publishes a new pair (csrc/params_handoff.h)."""
+        a = np.zeros(1, np.uint64)
+        check(self._L.mc_debug_read(self._h, 8 if published else 7, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return int(a[0])
+
     def debug_dims(self):
         d = (C.c_uint64 * 4)()
         check(self._L.mc_debug_read(self._h, 1, 0, None, 0, 0, d))
