@@ -49,7 +49,7 @@ struct ParamHandoff {
 
     // ---- writers -----------------------------------------------------------------------------------------------
     // f(cc[2]) edits the current pair in place; fields it leaves alone keep their values.  Returns the generation
-    // of the pair it published.  vsteps: if f changed cc[i].vsteps, the new value is stored (a select's reset, or
+    // of the pair it published (an edit that changes nothing publishes nothing).  vsteps: if f changed cc[i].vsteps, the new value is stored (a select's reset, or
     // mc_set_params handing the host's count over); otherwise the process path's count-down is left alone.
     template <class F>
     uint64_t update(F&& f) {
@@ -59,7 +59,9 @@ struct ParamHandoff {
         load_words(slot[c], cc);
         uint64_t vs_before[2];
         for (int i = 0; i < 2; i++) cc[i].vsteps = vs_before[i] = vsteps[i].load(std::memory_order_acquire);
+        mc_cc_value before[2] = {cc[0], cc[1]};
         f(cc);
+        if (same(before[0], cc[0]) && same(before[1], cc[1])) return slot[c].gen.load(std::memory_order_relaxed);  // nothing moved: nothing to publish
         for (int i = 0; i < 2; i++)
             if (cc[i].vsteps != vs_before[i]) vsteps[i].store(cc[i].vsteps, std::memory_order_release);  // before the pair: a reader that sees the new select sees the reset
         Slot& n = slot[1 - c];
@@ -102,6 +104,10 @@ struct ParamHandoff {
     }
 
 private:
+    static bool same(const mc_cc_value& a, const mc_cc_value& b) {  // (field by field: the struct has padding)
+        return a.select == b.select && a.predelay == b.predelay && a.speed == b.speed && a.vsteps == b.vsteps && a.dry == b.dry && a.wet == b.wet &&
+               a.panDry == b.panDry && a.panWet == b.panWet && a.level == b.level;
+    }
     static void load_words(const Slot& s, mc_cc_value (&cc)[2]) {
         uint64_t raw[kWords];
         for (int k = 0; k < kWords; k++) raw[k] = s.w[k].load(std::memory_order_relaxed);
