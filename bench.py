@@ -82,8 +82,11 @@ def parse():
     ap.add_argument("--exchange", choices=["gather", "none"], default="none",
                     help="block slices: leave every rank's finished slice on the GPU that computed it (default: like the "
                          "inputs, the outputs of the batch path live in HBM) or gather the slices on rank 0 over RCCL")
-    ap.add_argument("--collective", choices=["reduce", "allreduce"], default="reduce",
-                    help="partition shards: sum of partial wet blocks to rank 0 (default) or to every rank")
+    ap.add_argument("--collective", choices=["reduce_scatter", "reduce", "allreduce"], default="reduce_scatter",
+                    help="partition shards: how the partial wet blocks are summed. reduce_scatter (default): every rank receives "
+                         "and finishes the sum for its 1/N of the batch's blocks (mc_finish_batch_slice_device); reduce: the whole "
+                         "sum to rank 0, which finishes the batch (the round-2 form: N - 1 ranks' partials funnel into one GPU); "
+                         "allreduce: the whole sum to every rank")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--pipeline", action="store_true",
                     help="mc_config.pipeline: post stage of batch k on a second stream under the MAC of batch k + 1")
@@ -290,7 +293,8 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if a.backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a card
-        a.collective = "allreduce"                  # gloo has no reduce on device tensors
+        if a.collective == "reduce":
+            a.collective = "allreduce"              # gloo has no reduce on device tensors (reduce_scatter: emulated below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sharded = world > 1 or a.force_sharded
@@ -793,22 +797,60 @@ def main():
         if pe <= pb:
             raise SystemExit("empty shard; use fewer ranks")
         T = preferred(*shard_bounds(P, shard_world, 0))  # the same batch length on every rank: rank 0's shard decides
+        coll = a.collective
+        if coll == "reduce_scatter" and T % shard_world:
+            coll = "reduce"  # (the slices of a reduce-scatter are equal runs of whole blocks)
+        rs = coll == "reduce_scatter"
+        root_only_ = coll == "reduce"
+        Ts = T // shard_world if rs else T          # blocks this rank finishes
+        first = rank * Ts if rs else 0
         eng = Pairs(a, local, npairs, T, part_begin=pb, part_end=pe)
         xs, d_in = make_inputs(T)
-        d_out = [torch.zeros(2, T * BLOCK, device=dev) for _ in range(npairs)]
-        # the partial wet blocks of all pairs of a rank travel in ONE collective per batch
-        d_parts = [torch.zeros(npairs, 2 * T * BLOCK, device=dev) for _ in range(2)]
+        d_out = [torch.zeros(2, Ts * BLOCK, device=dev) for _ in range(npairs)]
+        # the partial wet blocks of all pairs of a rank: [pair][channel][T * 256]
+        d_parts = [torch.zeros(npairs, 2, T * BLOCK, device=dev) for _ in range(2)]
+        d_sums = [torch.zeros(npairs, 2, Ts * BLOCK, device=dev) for _ in range(2)] if rs else None
         torch.cuda.synchronize()
         for e in eng:
             e.use_torch_stream(comp)
         pending = []
         kept = None
 
+        class _Works:
+            def __init__(self, ws):
+                self.ws = ws
+
+            def wait(self):
+                for w in self.ws:
+                    if w is not None:
+                        w.wait()  # makes the compute stream wait for the collective; the host does not block
+
+        def collective(part, ssum):
+            if rs:
+                ws = []
+                for p in range(npairs):
+                    for c in range(2):  # one reduce-scatter per channel half: its N equal runs of blocks are the ranks' slices
+                        if world == 1:  # (one rank: the "sum" is the rank's own partial)
+                            ssum[p, c].copy_(part[p, c, first * BLOCK:(first + Ts) * BLOCK])
+                        elif a.backend == "gloo":  # rehearsal: gloo has no reduce-scatter on device tensors
+                            h = part[p, c].cpu()
+                            dist.all_reduce(h)
+                            ssum[p, c].copy_(h[first * BLOCK:(first + Ts) * BLOCK])
+                        else:
+                            ws.append(dist.reduce_scatter_tensor(ssum[p, c], part[p, c], async_op=True))
+                return _Works(ws)
+            if root_only_:
+                return _Works([dist.reduce(part, dst=0, async_op=True)])
+            return _Works([dist.all_reduce(part, async_op=True)])
+
         def retire():
-            work, part, o = pending.pop(0)
-            work.wait()  # makes the compute stream wait for the collective; the host does not block
+            work, part, ssum, o = pending.pop(0)
+            work.wait()
             for p, e in enumerate(eng):
-                if rank == 0 or not root_only:
+                if rs:
+                    e.finish_slice_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), ssum[p].data_ptr(),
+                                          d_out[p][0].data_ptr(), d_out[p][1].data_ptr(), T, first, Ts)
+                elif rank == 0 or not root_only_:
                     e.finish_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), part[p].data_ptr(),
                                     d_out[p][0].data_ptr(), d_out[p][1].data_ptr(), T)
                 else:
@@ -816,19 +858,17 @@ def main():
             if kept is not None and rank == 0:
                 kept.append(d_out[0].clone())
 
-        def step(k):
+        def step(k, with_collective=True):
             o = (k % n_distinct) * T * BLOCK
             part = d_parts[k % 2]
+            ssum = d_sums[k % 2] if rs else None
             for p, e in enumerate(eng):
                 e.partial_device(d_in[p][0, o:].data_ptr(), d_in[p][1, o:].data_ptr(), part[p].data_ptr(), T)
-            if root_only:
-                work = dist.reduce(part, dst=0, async_op=True)
-            else:
-                work = dist.all_reduce(part, async_op=True)
-            # the reduce of batch k overlaps the kernels of batch k + 1: batch k - 1 is finished now
+            work = collective(part, ssum) if with_collective else _Works([])
+            # the sum of batch k overlaps the kernels of batch k + 1: batch k - 1 is finished now
             if pending and not a.no_overlap:
                 retire()
-            pending.append((work, part, o))
+            pending.append((work, part, ssum, o))
             if a.no_overlap:
                 retire()
 
@@ -838,8 +878,25 @@ def main():
 
         dt, npre = timed(step, drain, a.steps, a.warmup, a.prewarm_ms)
         lv = None
+        n = shard_world
+        sent = int(npairs * 2 * T * BLOCK * 4 * ((n - 1) / n if rs else (1.0 if root_only_ else 2.0 * (n - 1) / n)))
         res = {"T": T, "dt": dt, "rtf": a.steps * T * BLOCK / FS / dt, "partitions_per_rank": pe - pb, "prewarm_steps": npre,
-               "reduce_bytes_per_step": int(npairs * 2 * T * BLOCK * 4)}
+               "collective": coll, "blocks_finished_per_rank": Ts, "reduce_bytes_per_step": int(npairs * 2 * T * BLOCK * 4),
+               "reduce_bytes_per_rank_per_step": sent}
+        # what the first hardware run should explain by itself: the kernels alone, the collective alone, and which one binds
+        if world > 1 and a.backend == "nccl":
+            nk = max(4, min(a.steps, 20))
+            dt_comp, _ = timed(lambda k: step(k, with_collective=False), drain, nk, 2)
+            part, ssum = d_parts[0], (d_sums[0] if rs else None)
+
+            def only_collective(k):
+                collective(part, ssum).wait()
+
+            dt_coll, _ = timed(only_collective, lambda: None, nk, 2)
+            res["kernels_only_ms_per_step"] = round(dt_comp / nk * 1e3, 4)
+            res["collective_only_ms_per_step"] = round(dt_coll / nk * 1e3, 4)
+            res["collective_GBps_per_rank"] = round(sent / (dt_coll / nk) / 1e9, 2)
+            res["link_bound"] = bool(dt_coll > dt_comp)
         if not a.no_check:
             for e in eng:
                 e.reset()
@@ -856,10 +913,12 @@ def main():
                 refs = unsharded_reference(T, nchk, d_in[0], 0)
                 num = den = 0.0
                 for k in range(nchk):
-                    num += float(((kept[k] - refs[k]).double() ** 2).sum())
-                    den += float((refs[k].double() ** 2).sum())
+                    want = refs[k][:, first * BLOCK:(first + Ts) * BLOCK]
+                    num += float(((kept[k] - want).double() ** 2).sum())
+                    den += float((want.double() ** 2).sum())
                 n_el = nchk * kept[0].numel()
-                res["sharded_check"] = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5}
+                res["sharded_check"] = {"batches": nchk, "rms_err_vs_unsharded": (num / n_el) ** 0.5, "rms_signal": (den / n_el) ** 0.5,
+                                        "blocks_checked_per_batch": Ts}
             kept = None
             if world > 1:
                 dist.barrier()
@@ -987,14 +1046,16 @@ def main():
         par_blocks = (f"dp{world}: output blocks of every batch sliced over {world} GPU(s) ({rb['count']} blocks each; every GPU holds "
                       f"the whole IR set and transforms the input its windows reach); no data-path collective, "
                       + (f"slices gathered to rank 0 ({ex})" if a.exchange == "gather" else "slices left on their ranks")) if rb else None
-        par_parts = (f"IR partitions sharded over {world} GPU(s) ({rp['partitions_per_rank']} of {P} per rank) + {ex} {a.collective} of the "
-                     f"partial wet blocks ({rp['reduce_bytes_per_step'] / 1e6:.0f} MB per step), overlapped with the next batch") if rp else None
+        par_parts = (f"IR partitions sharded over {world} GPU(s) ({rp['partitions_per_rank']} of {P} per rank) + {ex} {rp['collective']} of the "
+                     f"partial wet blocks ({rp['reduce_bytes_per_step'] / 1e6:.0f} MB of partials per rank and step, "
+                     f"{rp['reduce_bytes_per_rank_per_step'] / 1e6:.0f} MB of them leave the rank; every rank finishes "
+                     f"{rp['blocks_finished_per_rank']} of the {rp['T']} blocks), overlapped with the next batch") if rp else None
         why = ("`value` is the block-sliced layout: given the input, the output blocks of a batch are independent units, so they "
                "shard with no exchange step at all; the north-star layout (partition shards + RCCL sum) is measured in the same "
                "run under north_star_layout. It cannot scale batch throughput on this engine: the sum over partitions is a "
                "transform along the block axis whose cost does not depend on the number of partitions, so every rank still does "
-               "the whole forward / second-level / inverse work and the step only gains a 66 MB reduce; it is the layout for IR "
-               "sets that do not fit one GPU.")
+               "the whole forward / second-level / inverse work and the step only gains the exchange of the partials (a "
+               "reduce-scatter: each rank receives and finishes 1/N of the blocks); it is the layout for IR sets that do not fit one GPU.")
         line.update({
             "value": round(main_r["rtf"], 2),
             "ms_per_step": round(main_r["dt"] / a.steps * 1e3, 4),
@@ -1009,7 +1070,11 @@ def main():
             ns = {"value": round(rp["rtf"], 2), "unit": "x realtime", "ms_per_step": round(rp["dt"] / a.steps * 1e3, 4),
                   "scaling": "strong", "blocks_per_step": rp["T"], "parallelism": par_parts,
                   "sum_over_partitions": rp["sum_over_partitions"],
-                  "reduce_GBps": round(rp["reduce_bytes_per_step"] * a.steps / rp["dt"] / 1e9, 2)}
+                  "collective": rp["collective"], "reduce_bytes_per_rank_per_step": rp["reduce_bytes_per_rank_per_step"],
+                  "reduce_GBps": round(rp["reduce_bytes_per_rank_per_step"] * a.steps / rp["dt"] / 1e9, 2)}
+            for k in ("kernels_only_ms_per_step", "collective_only_ms_per_step", "collective_GBps_per_rank", "link_bound"):
+                if k in rp:
+                    ns[k] = rp[k]
             if "sharded_check" in rp:
                 ns["sharded_check"] = rp["sharded_check"]
             if by_blocks:

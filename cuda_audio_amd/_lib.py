@@ -20,7 +20,7 @@ SYMBOLS = [
     "mc_abi_version", "mc_last_error", "mc_default_config", "mc_default_params", "mc_create", "mc_destroy",
     "mc_reset", "mc_set_period", "mc_load_ir", "mc_num_irs", "mc_ir_info", "mc_set_params", "mc_get_params", "mc_handle_cc",
     "mc_process", "mc_process_batch", "mc_process_batch_device", "mc_partial_batch_device",
-    "mc_finish_batch_device", "mc_process_batch_slice_device", "mc_sync", "mc_fence", "mc_fence_older", "mc_set_stream", "mc_get_stream", "mc_avg_runtime_ms",
+    "mc_finish_batch_device", "mc_finish_batch_slice_device", "mc_process_batch_slice_device", "mc_sync", "mc_fence", "mc_fence_older", "mc_set_stream", "mc_get_stream", "mc_avg_runtime_ms",
     "mc_enable_kernel_timing", "mc_get_kernel_stats", "mc_algorithmic_bytes_per_block", "mc_blocks_processed", "mc_preferred_batch",
     "mc_debug_read", "mc_host_alloc", "mc_host_free",
 ]
@@ -121,6 +121,7 @@ def load():
     L.mc_process_batch_slice_device.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64]
     L.mc_partial_batch_device.argtypes = [vp, vp, vp, vp, u64]
     L.mc_finish_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, u64]
+    L.mc_finish_batch_slice_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, u64, u64]
     L.mc_sync.argtypes = [vp]
     L.mc_fence.argtypes = [vp]
     L.mc_fence_older.argtypes = [vp]

@@ -1381,7 +1381,10 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
                                               float* __restrict__ outL, float* __restrict__ outR, int T, int64_t tabs0,
                                               int first, int count, int64_t win0, int64_t predelay, int64_t n_ref, int compat,
                                               TailDrop td, int pm, Retired ret, unsigned* __restrict__ done_flag, unsigned seq,
-                                              unsigned* __restrict__ done_ctr) {
+                                              unsigned* __restrict__ done_ctr, int64_t lin_stride, int lin_first) {
+    // lin (partition shards): the summed partial, [2][lin_stride] floats whose first frame is block lin_first of the batch
+    // (the whole batch: lin_stride = T * 256, lin_first = 0; a rank that received its slice of a reduce-scatter:
+    // lin_stride = count * 256, lin_first = first)
     // done_flag (mapped host memory) != null: outL/outR are host buffers and the last workgroup to finish
     // publishes `seq` once every workgroup's output is visible to the host (one JACK period of 512 / 1024 frames)
     // T blocks in the batch starting at absolute block tabs0; this launch finishes blocks first .. first + count - 1
@@ -1398,7 +1401,8 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
         const int64_t tau_0 = tau0 + i0;
         float wl[4], wr_[4];
         if (lin) {  // shards: the sum over ranks of k_ola's output (predelay and retired partition sums included)
-            const float4 a = *reinterpret_cast<const float4*>(lin + i0), b = *reinterpret_cast<const float4*>(lin + (size_t)T * MC_B + i0);
+            const int64_t l0 = i0 - (int64_t)lin_first * MC_B;
+            const float4 a = *reinterpret_cast<const float4*>(lin + l0), b = *reinterpret_cast<const float4*>(lin + lin_stride + l0);
             wl[0] = a.x, wl[1] = a.y, wl[2] = a.z, wl[3] = a.w;
             wr_[0] = b.x, wr_[1] = b.y, wr_[2] = b.z, wr_[3] = b.w;
         } else {

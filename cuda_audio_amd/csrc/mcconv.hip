@@ -1514,11 +1514,17 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 // Q1/Q2 prefix sums, predelay, clamp, dry mix of the oldest batch in flight.
 // d_outL == null: the caller does not need this engine's output (a non-root
 // rank of a reduce-to-root): nothing is launched, the batch is just retired.
+// lin_first / lin_count >= 0 (partition shards after a reduce-scatter): lin_sum holds only blocks [lin_first, lin_first +
+// lin_count) of the summed partial, [2][lin_count * 256], and only those blocks are finished (into d_outL / d_outR, which
+// start at block lin_first); the Q1/Q2 prefix sums still run over the whole batch - every shard keeps that history.
 int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* lin_sum, float* d_outL, float* d_outR, int T,
-             bool publish = false) {  // publish: the buffers are mapped host memory; raise the completion flag
+             bool publish = false, int lin_first = -1, int lin_count = -1) {  // publish: the buffers are mapped host memory; raise the completion flag
     if (!e->pipe_count) return fail(MC_ERR_STATE, "no batch awaits its second half");
     const mc_engine::BatchCtx ctx = e->pipe[e->pipe_head];
     if (ctx.T != T) return fail(MC_ERR_ARG, "finish of %d blocks but the pending batch has %d", T, ctx.T);
+    const bool lin_slice = lin_first >= 0;
+    if (lin_slice && (!lin_sum || lin_count <= 0 || lin_first + lin_count > T || lin_first % e->pm || lin_count % e->pm))
+        return fail(MC_ERR_ARG, "slice [%d, %d) of the summed partial outside the batch of %d blocks (or not whole periods)", lin_first, lin_first + lin_count, T);
     e->pipe_head = (e->pipe_head + 1) % kPipe;
     e->pipe_count--;
     if (d_outL && d_outR) {
@@ -1552,14 +1558,16 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         }
         const TailDrop td = make_taildrop(e, ctx.vir, ctx.predelay);
         // the front half finished blocks >= out_from itself: only the blocks the predelay fills from the previous batch remain
-        const int post_count = ctx.out_from >= 0 ? ctx.out_from : ctx.count;
+        const int post_first = lin_slice ? lin_first : ctx.first;
+        const int post_count = lin_slice ? lin_count : (ctx.out_from >= 0 ? ctx.out_from : ctx.count);
         if (post_count > 0)
         hipLaunchKernelGGL(td.on ? k_post<true> : k_post<false>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
-                           e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, ctx.first, post_count,
+                           e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, post_first, post_count,
                            ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
                            td, e->pm, make_retired(e), publish ? e->hd_flag : (unsigned*)nullptr,
-                           publish ? ++e->flag_seq : 0u, e->d_done_ctr);
+                           publish ? ++e->flag_seq : 0u, e->d_done_ctr, lin_slice ? (int64_t)lin_count * MC_B : (int64_t)T * MC_B,
+                           lin_slice ? lin_first : 0);
         HIP_TRY(hipGetLastError());
         if (piped) {
             HIP_TRY(hipEventRecord(e->ev_post[ctx.slot], e->post_stream));
@@ -2879,6 +2887,17 @@ int mc_finish_batch_device(mc_engine* e, const float* d_in1, const float* d_in2,
     const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
     if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks outside range");
     return run_back(e, d_in1, d_in2, d_wet_sum, want_out ? d_outL : nullptr, d_outR, T);
+}
+
+int mc_finish_batch_slice_device(mc_engine* e, const float* d_in1, const float* d_in2, const float* d_wet_sum_slice, float* d_outL,
+                                 float* d_outR, uint64_t nblocks, uint64_t first, uint64_t count) {
+    if (!e || !d_in1 || !d_in2 || !d_wet_sum_slice || !d_outL || !d_outR) return fail(MC_ERR_ARG, "null argument");
+    if (e->sf) return fail(MC_ERR_ARG, "the single-transform form has no partition shards");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (int)std::min<uint64_t>(nblocks, 1u << 30);
+    if (T <= 0 || T > e->Tmax) return fail(MC_ERR_ARG, "nblocks outside range");
+    if (first >= (uint64_t)T || count == 0 || count > (uint64_t)T - first) return fail(MC_ERR_ARG, "slice outside the batch");
+    return run_back(e, d_in1, d_in2, d_wet_sum_slice, d_outL, d_outR, T, false, (int)first, (int)count);
 }
 
 int mc_sync(mc_engine* e) {

@@ -195,6 +195,10 @@ class Convolution:
     def finish_device(self, d_in1, d_in2, d_wet_sum, d_outL, d_outR, nblocks):
         check(self._L.mc_finish_batch_device(self._h, d_in1, d_in2, d_wet_sum, d_outL, d_outR, nblocks))
 
+    def finish_slice_device(self, d_in1, d_in2, d_wet_sum_slice, d_outL, d_outR, nblocks, first, count):
+        """The finish after a reduce-scatter: d_wet_sum_slice = [L | R] of blocks [first, first + count) only."""
+        check(self._L.mc_finish_batch_slice_device(self._h, d_in1, d_in2, d_wet_sum_slice, d_outL, d_outR, nblocks, first, count))
+
     def sync(self):
         check(self._L.mc_sync(self._h))
 

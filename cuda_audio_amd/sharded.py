@@ -128,8 +128,29 @@ class HipShard:
         self.conv.finish_device(x[0].data_ptr(), x[1].data_ptr(), wet_sum.data_ptr(), out[0].data_ptr(),
                                 out[1].data_ptr(), nblocks)
 
+    def finish_slice(self, x, wet_sum_slice, out_slice, nblocks, first, count):
+        """wet_sum_slice / out_slice: [2, count * 256], blocks [first, first + count) of the batch (after a reduce-scatter)."""
+        self.conv.finish_slice_device(x[0].data_ptr(), x[1].data_ptr(), wet_sum_slice.data_ptr(), out_slice[0].data_ptr(),
+                                      out_slice[1].data_ptr(), nblocks, first, count)
+
     def close(self):
         self.conv.close()
+
+
+def reduce_scatter_channels(part2, ssum, rank, world, group=None):
+    """Sum over ranks of the [2, n] partials, scattered by runs of blocks: rank r receives [2, n / world] = its run of
+    both channel halves (one reduce-scatter per channel: a channel half is the concatenation of the ranks' runs).
+    Backends without a reduce-scatter on these tensors (gloo) take an all-reduce and keep their run."""
+    import torch.distributed as dist
+
+    n = part2.shape[1] // world
+    for c in range(2):
+        try:
+            dist.reduce_scatter_tensor(ssum[c], part2[c], op=dist.ReduceOp.SUM, group=group)
+        except (RuntimeError, NotImplementedError):
+            tmp = part2[c].clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+            ssum[c].copy_(tmp[rank * n:(rank + 1) * n])
 
 
 class ShardedConvolution:
@@ -138,10 +159,34 @@ class ShardedConvolution:
     oracle-backed one); `group` is a torch.distributed process group or None for
     a single rank."""
 
-    def __init__(self, shard, world=1, group=None):
+    def __init__(self, shard, world=1, group=None, rank=0):
         self.shard = shard
         self.world = world
         self.group = group
+        self.rank = rank
+
+    def process_scattered(self, x, out_slice, part=None):
+        """The north-star layout with a reduce-scatter as its one exchange: every rank sums its shard of the partitions
+        over the whole batch, receives the sum over ranks for ITS run of nblocks / world blocks, and finishes that run
+        (mc_finish_batch_slice_device) into out_slice [2, n / world].  No rank is a root; each link carries 1/world of
+        what a reduce to one root funnels into it.  Returns (first, count) of the blocks in out_slice."""
+        n = x.shape[1]
+        nblocks = n // BLOCK
+        if n % BLOCK or nblocks % self.world:
+            raise ValueError("the batch must be whole blocks and split evenly over the ranks")
+        count = nblocks // self.world
+        first = self.rank * count
+        if part is None:
+            part = torch.empty(2 * n, dtype=out_slice.dtype, device=x.device)
+        self.shard.partial(x, part, nblocks)
+        p2 = part.view(2, n)
+        if self.world > 1:
+            ssum = torch.empty(2, count * BLOCK, dtype=part.dtype, device=part.device)
+            reduce_scatter_channels(p2, ssum, self.rank, self.world, self.group)
+        else:
+            ssum = p2
+        self.shard.finish_slice(x, ssum.contiguous(), out_slice, nblocks, first, count)
+        return first, count
 
     def process(self, x, out, part=None):
         """x: [2, n] input (same on every rank), out: [2, n] output, n = nblocks * 256.

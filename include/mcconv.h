@@ -107,8 +107,10 @@ typedef struct {
     uint32_t resident;      /* 1 = the last launch used the resident (batch) kernel */
     uint32_t partitions;    /* partitions swept per block by the last launch */
     uint32_t fast_levels;   /* how the last long batch summed its partitions: 0 = direct-form MAC, 1..3 = fast-FIR form
-                               with that many nested levels ((3/4)^levels of the multiply-adds), 255 = second-level
-                               transform along the block axis instead of the MAC */
+                               with that many nested levels ((3/4)^levels of the multiply-adds); second-level transform
+                               along the block axis instead of the MAC: 254 = its fused 8192-point form (one launch,
+                               k_g2_mac: the default for long batches with one set of gains), 255 = its split 16384-point
+                               form (k_f2_fwd + k_f2_prod: per-slot gains, IRs over 5632 partitions) */
     uint32_t reserved;
 } mc_kernel_stats;
 
@@ -180,6 +182,16 @@ int mc_process_batch_slice_device(mc_engine *e, const float *d_in1, const float 
 int mc_partial_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, float *d_partial, uint64_t nblocks);
 int mc_finish_batch_device(mc_engine *e, const float *d_in1, const float *d_in2, const float *d_wet_sum,
                            float *d_outL, float *d_outR, uint64_t nblocks);
+/* The finish after a REDUCE-SCATTER instead of a reduce: every shard receives the sum of the partials for ITS run of
+ * blocks [first, first + count) only - d_wet_sum_slice = [L | R], count * 256 floats each (e.g. one reduce-scatter per
+ * channel over the [nblocks * 256] channel halves of the partials) - and finishes those blocks into d_outL / d_outR
+ * (count * 256 floats each).  d_in1 / d_in2 are the whole batch's inputs, as passed to mc_partial_batch_device.  Every
+ * shard then keeps the Q1/Q2 history (it transforms the whole input anyway), no rank is a root, and each link carries
+ * 1/N of what a reduce to one root funnels into that root.  first and count are multiples of period/256.  Retires the
+ * batch like mc_finish_batch_device; an engine should use one of the two finishes throughout.  No reference
+ * equivalent (the reference runs on one device, gpu.cu:38-90). */
+int mc_finish_batch_slice_device(mc_engine *e, const float *d_in1, const float *d_in2, const float *d_wet_sum_slice,
+                                 float *d_outL, float *d_outR, uint64_t nblocks, uint64_t first, uint64_t count);
 
 int mc_sync(mc_engine *e);
 /* pipelined engines: the engine's stream waits for everything issued so far (no host synchronisation) */
@@ -209,7 +221,9 @@ uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
 /* Diagnostics (tests only): copy `bytes` from an engine-owned device buffer to host.
  * which: 0 = IR spectra of IR `idx` (float4 [256][pstride]), 1 = delay line
  * (float4 [256][ring]), 2 = MAC output (float4 [256][max_batch]), 3 = segments,
- * 4 = wet ring, 5 = Q1/Q2 prefix ring (double [rc][4]).  dims[0..3] receive
+ * 4 = wet ring, 5 = Q1/Q2 prefix ring (double [rc][4]); host-side words, no stream access: 6 = JACK-path counters
+ * {parked periods used, gave up on their own, told to give up} (3 x uint64), 7 / 8 = generation of the parameter
+ * pair the last process call sampled / that was published last (uint64).  dims[0..3] receive
  * {pstride, ring, max_batch, wet ring length} when non-null. */
 int mc_debug_read(mc_engine *e, int which, uint64_t idx, void *dst, uint64_t offset_bytes, uint64_t bytes,
                   uint64_t dims[4]);

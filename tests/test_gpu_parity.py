@@ -1714,6 +1714,92 @@ def test_config4_partition_shards_at_full_size(oracle_mod, gpu_lib, monkeypatch)
         assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"
 
 
+def test_partition_shards_finish_their_runs_after_a_reduce_scatter(oracle_mod, gpu_lib, monkeypatch):
+    """The north-star layout with a reduce-scatter as its exchange (mc_finish_batch_slice_device): four virtual ranks on
+    one GPU, 10 s IRs (1723 partitions, 432 per shard), batches of the shards' preferred length.  Every shard sums its
+    partitions over the whole batch; the sum over shards stands in for the collective; shard g receives the sum for ITS
+    quarter of the blocks only - [L | R] of that run - and finishes it: Q1/Q2 window sums from its own prefix ring (every
+    shard keeps that history now), predelay already in the partials, clamp, dry mix.  The four runs together are, bit
+    for bit, what one root finishing the whole sum gives (mc_finish_batch_device on a fifth set of shards), and the
+    range oracle's samples (conv.cu:392-427) - also across the batch boundary, where the second batch's Q1/Q2 windows
+    reach back into the first."""
+    import torch
+
+    from cuda_audio_amd.sharded import shard_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    monkeypatch.setenv("MCCONV_FFT2", "1")
+    monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
+    dev = torch.device("cuda:0")
+    n_ref, G = 524288, 4
+    irs = [make_ir(441000, seed=5678), make_ir(441000, seed=5680)]
+    p0, p1 = dict(BASE, select=0, predelay=300, panDry=0.2), dict(BASE, select=1, panWet=0.25)
+    bounds = [shard_bounds(1723, G, g) for g in range(G)]
+    assert bounds[0] == (0, 432) and bounds[-1][1] == 1728
+
+    def make_shards():
+        out = [_conv(fftSize=n_ref, max_batch=16384, part_begin=a, part_end=b) for a, b in bounds]
+        for s in out:
+            for i, ir in enumerate(irs):
+                s.prepare(i, ir)
+            apply_params(s, p0, p1, False)
+        return out
+
+    scat, root = make_shards(), make_shards()
+    T = scat[0].preferred_batch(16384)
+    assert T % G == 0
+    Ts = T // G
+    x = make_input(2 * T * 256)
+    x[0] += 0.05  # DC and an alternating component: the Q1/Q2 sums matter
+    x[1, ::2] += 0.04
+    xin = torch.from_numpy(x).to(dev)
+    got = np.zeros((2, 2 * T * 256), np.float32)
+    want_root = np.zeros_like(got)
+    for k in range(2):
+        sl = xin[:, k * T * 256:(k + 1) * T * 256]
+        totals = []
+        for group in (scat, root):
+            total = torch.zeros(2 * T * 256, device=dev)
+            for s in group:
+                part = torch.zeros(2 * T * 256, device=dev)
+                s.partial_device(sl[0].data_ptr(), sl[1].data_ptr(), part.data_ptr(), T)
+                s.sync()
+                total += part
+            totals.append(total)
+        assert torch.equal(totals[0], totals[1])
+        t2 = totals[0].view(2, T * 256)
+        for g, s in enumerate(scat):  # "reduce-scatter": rank g gets its run of both channel halves
+            mine = t2[:, g * Ts * 256:(g + 1) * Ts * 256].contiguous()
+            out = torch.full((2, Ts * 256), float("nan"), device=dev)
+            s.finish_slice_device(sl[0].data_ptr(), sl[1].data_ptr(), mine.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), T, g * Ts, Ts)
+            s.sync()
+            got[:, (k * T + g * Ts) * 256:(k * T + (g + 1) * Ts) * 256] = out.cpu().numpy()
+        out = torch.zeros(2, T * 256, device=dev)
+        root[0].finish_device(sl[0].data_ptr(), sl[1].data_ptr(), totals[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), T)
+        root[0].sync()
+        for s in root[1:]:
+            s.finish_device(None, None, None, None, None, T)
+        want_root[:, k * T * 256:(k + 1) * T * 256] = out.cpu().numpy()
+    # argument errors: a run outside the batch, and a finish with nothing pending
+    e = scat[0]
+    with pytest.raises(Exception):
+        e.finish_slice_device(xin[0].data_ptr(), xin[1].data_ptr(), xin.data_ptr(), xin.data_ptr(), xin.data_ptr(), T, T - 1, 2)
+    with pytest.raises(Exception):
+        e.finish_slice_device(xin[0].data_ptr(), xin[1].data_ptr(), xin.data_ptr(), xin.data_ptr(), xin.data_ptr(), T, 0, Ts)
+    for s in scat + root:
+        s.close()
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, want_root)
+    for b0, n in ((Ts - 40, 80), (T - 60, 120), (T + 3 * Ts - 30, 60)):  # across runs, across the batch boundary
+        u = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            u.prepare(i, ir)
+        apply_params(u, p0, p1, True)
+        want = u.range(x[0], x[1], b0, n)
+        err = rms(got[:, b0 * 256:(b0 + n) * 256] - want)
+        assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"
+
+
 def test_q4_output_clamp_parts_from_the_reference_only_after_saturation(oracle_mod, gpu_lib):
     """Q4 (conv.cu:98), the one documented deviation: the engine clamps the finished wet sample, the reference its
     running accumulator.  With a loud IR the engine equals the partitioned oracle form (output clamp) everywhere and

@@ -49,6 +49,38 @@ class OracleShard:
         out.numpy()[:] = self.o.finish(xn[0], xn[1], wet_sum.view(2, -1).numpy())
 
 
+class OracleBatchShard:
+    """Test double for the reduce-scatter driver: HipShard's partial / finish_slice over a batch of blocks.  The oracle
+    advances block by block (partial, then finish), so one instance runs ahead to produce the batch's partials and a
+    second one replays the batch and finishes the rank's run of blocks with the summed partial."""
+
+    def __init__(self, n_ref, pb, pe, ir):
+        import oracle
+
+        self.a = oracle.Upols(n_ref, True, pb, pe)
+        self.b = oracle.Upols(n_ref, True, pb, pe)
+        self.a.prepare(0, ir)
+        self.b.prepare(0, ir)
+
+    def partial(self, x, part, nblocks):
+        xn, p = x.numpy(), part.view(2, -1).numpy()
+        for t in range(nblocks):
+            s = slice(t * 256, (t + 1) * 256)
+            p[:, s] = self.a.partial(xn[0, s], xn[1, s])
+            self.a.finish(xn[0, s], xn[1, s], p[:, s].copy())  # (advances the state; its output is not used)
+
+    def finish_slice(self, x, wet_sum_slice, out_slice, nblocks, first, count):
+        xn, w, o = x.numpy(), wet_sum_slice.numpy(), out_slice.numpy()
+        for t in range(nblocks):
+            s = slice(t * 256, (t + 1) * 256)
+            own = self.b.partial(xn[0, s], xn[1, s])
+            if first <= t < first + count:
+                d = slice((t - first) * 256, (t - first + 1) * 256)
+                o[:, d] = self.b.finish(xn[0, s], xn[1, s], w[:, d].copy())
+            else:
+                self.b.finish(xn[0, s], xn[1, s], own)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -99,6 +131,55 @@ def test_two_rank_gloo_sum_of_partials_equals_unsharded():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret["sig"] > 1e-3
     assert ret["err"] < 1e-14, ret["err"]
+
+
+def _scatter_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuda_audio_amd.synth import make_input, make_ir
+
+        nbat, T, n_ref = 3, 8, 16384
+        x = make_input(nbat * T * 256)
+        x[0] += 0.04  # (the Q1/Q2 sums matter: every rank must keep their history to finish its run)
+        ir = make_ir(9000, seed=3, norm=0.05)
+        P = partitions_for(len(ir), n_ref)
+        pb, pe = shard_bounds(P, world, rank)
+        drv = ShardedConvolution(OracleBatchShard(n_ref, pb, pe, ir), world=world, rank=rank)
+        count = T // world
+        mine = np.zeros((2, nbat * count * 256))
+        for k in range(nbat):
+            xb = torch.from_numpy(x[:, k * T * 256:(k + 1) * T * 256].copy())
+            ob = torch.zeros(2, count * 256, dtype=torch.float64)
+            f, c = drv.process_scattered(xb, ob, torch.zeros(2 * T * 256, dtype=torch.float64))
+            assert (f, c) == (rank * count, count)
+            mine[:, k * count * 256:(k + 1) * count * 256] = ob.numpy()
+        import oracle
+
+        full = oracle.Upols(n_ref, True)
+        full.prepare(0, ir)
+        want = full.process(x[0], x[1]).reshape(2, nbat, T * 256)[:, :, rank * count * 256:(rank + 1) * count * 256].reshape(2, -1)
+        ret[rank] = (float(np.sqrt(np.mean((mine - want) ** 2))), float(np.sqrt(np.mean(want ** 2))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduce_scatter_and_slice_finish_equals_unsharded():
+    """The north-star layout's exchange as a reduce-scatter: each rank sums its partition shard
+    over the whole batch, receives the sum for its half of the blocks and finishes them; every rank keeps the Q1/Q2
+    history.  Both ranks' runs equal the unsharded oracle's (gloo has no reduce-scatter: the driver falls back to
+    all-reduce + slice, the same sums)."""
+    import oracle
+
+    oracle.lib()
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_scatter_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        err, sig = ret[r]
+        assert sig > 1e-3 and err < 1e-14, (r, err, sig)
 
 
 def test_slice_bounds_tile_the_batch():
