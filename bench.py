@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on): stereo
 44.1 kHz, 256-frame blocks, 10 s / 441 000-tap IR (P = 1723 partitions,
 N_ref = 524288), reference routing (2 inputs x 2 outputs = 4 convolution
 paths), fp32.  One "step" = one batch of --blocks (default: the engine's
-preferred length, 32320) consecutive blocks pushed through forward FFT ->
+preferred length up to --max-blocks, 129296) consecutive blocks pushed through forward FFT ->
 sum over partitions -> inverse FFT -> overlap-add -> predelay / Q1-Q2 terms /
 clamp / dry mix, inputs and outputs resident in HBM.
 
@@ -55,14 +55,20 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=0,
                     help="blocks per step (batch length T). 0 (default): what the engine prefers up to --max-blocks "
-                         "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 129280 = 750 s "
+                         "(mc_preferred_batch: whole chunks of the second-level transform minus one halo block) - 129296 = 750 s "
                          "of audio = twenty chunks of 8192 - 1728 + 1 blocks for the 1723-partition IR")
     ap.add_argument("--max-blocks", type=int, default=131072,
                     help="upper limit of the preferred batch length (per GPU; eight block-sliced ranks then share a global batch "
-                         "of 8 x 129280 blocks, inside mc_config.max_batch <= 1048576). Longer batches amortise the launches' "
-                         "ramps and tails: 892 k x at 32320 blocks, 970 k x at 64640, 1.0 M x at 129280")
+                         "of 8 x 129296 blocks, inside mc_config.max_batch <= 1048576). Longer batches amortise the launches' "
+                         "ramps and tails: 892 k x at 32320 blocks, 970 k x at 64640, 1.0 M x at 129296")
     ap.add_argument("--taps", type=int, default=441000)
     ap.add_argument("--fft-size", type=int, default=524288, help="reference fftSize (N_ref)")
+    ap.add_argument("--predelay", type=int, default=0, help="predelay of both halves in frames (conv.h:26-28: 0..8192; SURVEY 8(d): 0 for perf)")
+    ap.add_argument("--same-ir", action="store_true", help="both halves select IR 0 (settings.txt:38,63 select one IR for both)")
+    ap.add_argument("--shipped-defaults", action="store_true",
+                    help="the operating point the reference ships (settings.txt:19,38-45): fftSize 131072, both halves on one IR, "
+                         "predelay 1024, an IR longer than fftSize - 1024 (14 of the shipped files): --fft-size 131072 --taps 130048 "
+                         "--predelay 1024 --same-ir. taps + 255 + predelay > fftSize: the Q8 tail-drop regime (k_post<true>, no fused output)")
     ap.add_argument("--channels", type=int, default=2, choices=[2, 4, 6, 8],
                     help="2 per `Convolution` object (main.cu:31-39): 8 = BASELINE config 4, four pairs with their own IRs")
     ap.add_argument("--mode", choices=["resident", "stream"], default="resident",
@@ -131,24 +137,61 @@ def cpu_threads():
     return n
 
 
+def fftw_probe():
+    """FFTW is not installed in the image; if a GPU box happens to carry libfftw3f, say so (it is only
+    reported: the baseline's transforms are the oracle's own, so that the number means the same thing on every box)."""
+    import ctypes
+    import ctypes.util
+
+    for name in (ctypes.util.find_library("fftw3f"), "libfftw3f.so.3", "libfftw3f.so"):
+        if not name:
+            continue
+        try:
+            ctypes.CDLL(name)
+            return f"found ({name}); not used: the baseline keeps the oracle's own radix-2 FFT"
+        except OSError:
+            continue
+    return "not found (dlopen of libfftw3f failed): the baseline uses the oracle's own radix-2 FFT"
+
+
 def cpu_baseline(ir, ir_b, x, seconds):
-    """oracle Cpu32 (float32 OpenMP partitioned overlap-save) on a bounded sample of the same workload:
-    chunks of 128 blocks until `seconds` of wall clock have passed."""
+    """SURVEY 8(d)'s CPU baseline, timed in this run on the box's host cores, on a bounded sample of the same workload:
+    oracle Cpu32 (float32 OpenMP partitioned overlap-save, own FFT) with all the cores this box may use - `value` - and
+    with one thread; the reference's own single-transform algorithm at config 2 (oracle RefCompat: one 131072-point
+    transform per call, float64, one thread); and whether FFTW could have been loaded."""
     import oracle
+    from cuda_audio_amd.synth import make_ir
 
     threads = cpu_threads()
     eng = oracle.Cpu32(ir, ir_b)
     g = np.array([0.5, 0.5, 0.5, 0.5], np.float32)
     chunk, avail = 128, x.shape[1] // BLOCK
-    eng.process(x[0, : chunk * BLOCK], x[1, : chunk * BLOCK], g, g, threads)  # warm-up, untimed
-    t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < seconds:
-        o = (done % max(avail - chunk, 1))
-        eng.process(x[0, o * BLOCK: (o + chunk) * BLOCK], x[1, o * BLOCK: (o + chunk) * BLOCK], g, g, threads)
-        done += chunk
-    dt = time.perf_counter() - t0
+
+    def run(nthreads, secs):
+        eng.process(x[0, : chunk * BLOCK], x[1, : chunk * BLOCK], g, g, nthreads)  # warm-up, untimed
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < secs:
+            o = (done % max(avail - chunk, 1))
+            eng.process(x[0, o * BLOCK: (o + chunk) * BLOCK], x[1, o * BLOCK: (o + chunk) * BLOCK], g, g, nthreads)
+            done += chunk
+        return done, time.perf_counter() - t0
+
+    done, dt = run(threads, 0.6 * seconds)
+    done1, dt1 = run(1, 0.25 * seconds)
     eng.close()
+    # config 2 in the reference's own shape on the CPU (what run_single_form's parity leg times, here beside the headline)
+    r = oracle.RefCompat(131072, True)
+    r.prepare(0, make_ir(88200, seed=5678))
+    r.prepare(1, make_ir(88200, seed=5680))
+    r.set(1, select=1)
+    ncall = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15 * seconds or ncall < 4:
+        r.process(x[0, ncall * BLOCK:(ncall + 1) * BLOCK], x[1, ncall * BLOCK:(ncall + 1) * BLOCK])
+        ncall += 1
+    dtr = time.perf_counter() - t0
+    r.close()
     return {
         "value": round(done * BLOCK / FS / dt, 3),
         "unit": "x realtime",
@@ -156,6 +199,12 @@ def cpu_baseline(ir, ir_b, x, seconds):
         "kind": "port",
         "sample": f"{done} blocks ({done * BLOCK / FS:.1f} s of audio) of the same stereo/{ir.shape[0]}-tap workload, "
                   f"oracle/oracle.c orc_cpu32 (own radix-2 FFT, OpenMP over bins), {dt:.1f} s wall",
+        "single_thread": {"value": round(done1 * BLOCK / FS / dt1, 3), "unit": "x realtime", "cores": 1,
+                          "sample": f"{done1} blocks of the same workload, one thread, {dt1:.1f} s wall"},
+        "refcompat_config2": {"value": round(ncall * BLOCK / FS / dtr, 3), "unit": "x realtime", "cores": 1,
+                              "sample": f"{ncall} calls of oracle/oracle.c orc_ref_process at BASELINE config 2 (88200-tap IRs, one 131072-point "
+                                        f"transform per 256-frame call, float64: the reference's algorithm on a CPU), {dtr:.1f} s wall"},
+        "fftw": fftw_probe(),
     }
 
 
@@ -267,12 +316,18 @@ class Pairs:
             e.close()
 
 
+_BP = {"predelay": 0, "same_ir": False}
+
+
 def bench_params(h):
-    return dict(select=h, predelay=0, dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
+    return dict(select=0 if _BP["same_ir"] else h, predelay=_BP["predelay"], dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
 
 
 def main():
     a = parse()
+    if a.shipped_defaults:
+        a.fft_size, a.taps, a.predelay, a.same_ir = 131072, 131072 - 1024, 1024, True
+    _BP["predelay"], _BP["same_ir"] = a.predelay, a.same_ir
     # The contract is ONE JSON line on stdout.  Libraries below us write there too (gloo's connection banner, RCCL
     # at some debug levels): from here on everything that goes to file descriptor 1 lands on stderr, and the JSON
     # line is written to the original stdout at the end.
@@ -546,8 +601,32 @@ def main():
             prev = ((a.steps - 2) % n_distinct) if a.steps >= 2 else ((max(a.warmup, 1) - 1) % n_distinct)
             reach = a.fft_size // BLOCK + 3
             before = (npre + max(a.warmup, 1) + a.steps - 2) * T  # blocks of the stream before the excerpt
+            q8 = min(a.taps, a.fft_size - 1024) + 255 + a.predelay > a.fft_size
             if a.precision != "fp32":
                 res["parity"] = {"skipped": "fp16 storage has its own bar (tests/test_gpu_parity.py: 2e-3 of the wet RMS)"}
+            elif q8:
+                # the Q8 tail-drop regime (what the reference ships): the range oracle does not model the dropped tails, the
+                # single-transform restatement of conv.cu does - from a cold start, a fresh engine, one batch of 160 blocks
+                import oracle
+
+                nchk = 160
+                e2 = Pairs(a, local, 1, nchk)
+                x = xs[0]
+                got = e2[0].process(x[0, :nchk * BLOCK], x[1, :nchk * BLOCK])
+                e2.close()
+                r = oracle.RefCompat(a.fft_size, True)
+                for i, ir in enumerate(eng.irs[0]):
+                    r.prepare(i, ir)
+                for h in range(2):
+                    r.set(h, **bench_params(h))
+                want = r.process(x[0, :nchk * BLOCK], x[1, :nchk * BLOCK])
+                r.close()
+                d = got.astype(np.float64) - want
+                err = float(np.sqrt(np.mean(d * d)))
+                res["parity"] = {"rms_err": err, "rms_signal": float(np.sqrt(np.mean(want * want))), "blocks": nchk, "tolerance": RMS_TOL,
+                                 "ok": bool(err <= RMS_TOL),
+                                 "oracle": "oracle/oracle.c orc_ref_process (float64 restatement of conv.cu:287-466 with the reference's own "
+                                           "buffers: the Q8 tail drop comes out of the restated code), cold start, a fresh engine, one batch"}
             elif T < reach + 64 or before < 400:
                 res["parity"] = {"skipped": f"steady-state excerpt needs batches of >= {reach + 64} blocks and a settled cross-fade"}
             else:
@@ -929,7 +1008,9 @@ def main():
 
     # ------------------------------------------------------------------ assemble the line
     workload = (f"{a.channels}-channel ({npairs} stereo pair(s), one Convolution object each) 44.1 kHz, 256-frame blocks, "
-                f"{a.taps}-tap IRs ({P} partitions, N_ref {a.fft_size}), 2x2 path matrix per pair")
+                f"{a.taps}-tap IRs ({P} partitions, N_ref {a.fft_size}), 2x2 path matrix per pair"
+                + (f", predelay {a.predelay}" if a.predelay else "") + (", both halves on one IR" if a.same_ir else "")
+                + (" [the reference's shipped operating point, settings.txt:19,38-45: Q8 tail-drop regime]" if a.shipped_defaults else ""))
     line = {
         "metric": "real-time factor (frames/s / 44.1k), stereo block=256, 10 s IR",
         "unit": "x realtime",

@@ -1358,6 +1358,284 @@ __device__ __forceinline__ void write_history(const TailDrop& td, int64_t tau, i
         td.gring[(size_t)m * rc + (size_t)(tblock & (rc - 1))] = make_float4(bp.g[m][0], bp.g[m][1], bp.g[m][2], bp.g[m][3]);
 }
 
+// The same terms for a TILE of output samples, by the whole workgroup (256 threads; contains barriers: every thread of
+// the workgroup calls it).  Round 3: the reference's SHIPPED operating point is in this regime (settings.txt:19,38-45:
+// fftSize 131072, predelay 1024 and 14 of the shipped IRs longer than fftSize - 1024), and with tail_drop() above - one
+// thread per output sample walking up to 256 input samples and taps through scattered loads - it ran 15x slower in
+// batches and 7x slower per JACK period than the same IR without the regime (profiles/r3_shipped_defaults.md).
+// Here the source block's 256 input samples and the stretch of taps the tile's samples can pair with them
+// (SPAN + 255 taps per input, zero outside [0, L): no bounds tests in the loop) are staged in LDS once per source block
+// and voice; a thread then walks the 256 input samples for its NS output samples.  With consecutive samples
+// (RSTRIDE = 1, k_post: four frames per lane) the taps slide through registers: one new tap pair per input sample
+// for 4 NS multiply-adds.  The order of summation per sample is tail_drop()'s (m ascending per source block).
+//   tau_tile: first sample of the tile; thread's samples: tau_tile + r0 + q RSTRIDE, q < NS (all inside one 256-frame
+//   block per q).  s_x: [2][256] floats, s_h: [2][SPAN + 256] float2 of LDS.
+template <int NS, int RSTRIDE, int SPAN>
+__device__ __forceinline__ void tail_drop_tile(const TailDrop& td, float* s_x, float2* s_h, int64_t tau_tile, int r0, bool active,
+                                               int64_t tau0, int T, int64_t pd, int64_t n_ref, const BlockParams* __restrict__ ptab,
+                                               int pstride, int rc, const float* cur1, const float* cur2, int pm, int64_t blo,
+                                               int64_t bhi, float (&dl)[NS], float (&dr)[NS]) {
+    constexpr int HW = SPAN + 256;
+#pragma unroll
+    for (int q = 0; q < NS; q++) dl[q] = dr[q] = 0.f;
+    const int64_t v_last = tau_tile + SPAN - 1 - n_ref;
+    if (v_last < 0) return;  // (uniform: the whole workgroup leaves)
+    int64_t hi_all = ((v_last >> 8) / pm + 1) * pm - 1;
+    const int64_t lo = tau_tile - pd - 254 - td.lmax;
+    int64_t lo_all = lo <= 0 ? 0 : ((lo + 255) >> 8);
+    if (lo_all < blo) lo_all = blo;
+    if (hi_all > bhi) hi_all = bhi;
+    int64_t hi_q[NS];  // last source block whose contribution this sample has lost (calls that started at or before tau - n_ref)
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+        const int64_t v = tau_tile + r0 + q * RSTRIDE - n_ref;
+        hi_q[q] = (active && v >= 0) ? ((v >> 8) / pm + 1) * pm - 1 : -1;
+        if (hi_q[q] > bhi) hi_q[q] = bhi;
+    }
+    const int tid = threadIdx.x;
+    for (int64_t tb = lo_all; tb <= hi_all; tb++) {
+        const int64_t base = tb << 8, rel = tb - (tau0 >> 8);
+        __syncthreads();  // (the previous source block's samples are no longer read)
+        {
+            const int64_t sig = base + tid;
+            float x1, x2;
+            if (sig >= tau0) {
+                x1 = cur1[sig - tau0];
+                x2 = cur2[sig - tau0];
+            } else {
+                x1 = td.xhist[(size_t)(sig & (td.xr - 1))];
+                x2 = td.xhist[(size_t)td.xr + (sig & (td.xr - 1))];
+            }
+            s_x[tid] = x1;
+            s_x[256 + tid] = x2;
+        }
+        const int64_t kb = tau_tile - pd - base - 255;  // tap index of window entry 0
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+            if (vi >= td.nv) break;
+            float4 g;
+            if (rel >= 0 && rel < T) {
+                const float* gv = ptab[rel * pstride].g[vi];
+                g = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            } else {
+                g = td.gring[(size_t)vi * rc + (size_t)(tb & (rc - 1))];
+            }
+            if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;  // (uniform)
+            __syncthreads();  // (the previous voice's taps are no longer read)
+            for (int e = tid; e < HW; e += 256) {
+                const int64_t k = kb + e;
+                s_h[e] = (k >= 0 && k < td.L0[vi]) ? td.h0[vi][k] : make_float2(0.f, 0.f);
+                s_h[HW + e] = (k >= 0 && k < td.L1[vi]) ? td.h1[vi][k] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            float aL0[NS], aR0[NS], aL1[NS], aR1[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) aL0[q] = aR0[q] = aL1[q] = aR1[q] = 0.f;
+            const int e0 = r0 + 255;  // window entry of (sample q = 0, input sample m = 0); entry of (q, m) = e0 + q RSTRIDE - m
+            // a wave whose samples cannot pair with this source block - it is not one they have lost, or every tap index
+            // tau - pd - 256 tb - m of the wave lies outside [0, L) - skips the walk (wave-uniform; the barriers stay outside)
+            bool work = false;
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const int64_t s_hi = tau_tile + r0 + q * RSTRIDE - pd - base;  // tap index at m = 0 (the largest of this sample)
+                work = work || (tb <= hi_q[q] && s_hi >= 0 && s_hi - 255 < (int64_t)td.lmax);
+            }
+            if (!__any(work)) {
+                // nothing to add
+            } else if (RSTRIDE == 1) {
+                float2 wa[NS], wb[NS];
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    wa[q] = s_h[e0 + q];
+                    wb[q] = s_h[HW + e0 + q];
+                }
+                for (int m = 0; m < MC_B; m++) {
+                    const float x1 = s_x[m], x2 = s_x[256 + m];
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+                        aL0[q] = fmaf(x1, wa[q].x, aL0[q]);
+                        aR0[q] = fmaf(x1, wa[q].y, aR0[q]);
+                        aL1[q] = fmaf(x2, wb[q].x, aL1[q]);
+                        aR1[q] = fmaf(x2, wb[q].y, aR1[q]);
+                    }
+#pragma unroll
+                    for (int q = NS - 1; q > 0; q--) {
+                        wa[q] = wa[q - 1];
+                        wb[q] = wb[q - 1];
+                    }
+                    const int en = e0 - (m + 1) < 0 ? 0 : e0 - (m + 1);  // (m = 255 at r0 = 0: nothing follows)
+                    wa[0] = s_h[en];
+                    wb[0] = s_h[HW + en];
+                }
+            } else {
+                for (int m = 0; m < MC_B; m++) {
+                    const float x1 = s_x[m], x2 = s_x[256 + m];
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+                        const float2 ha = s_h[e0 + q * RSTRIDE - m], hb = s_h[HW + e0 + q * RSTRIDE - m];
+                        aL0[q] = fmaf(x1, ha.x, aL0[q]);
+                        aR0[q] = fmaf(x1, ha.y, aR0[q]);
+                        aL1[q] = fmaf(x2, hb.x, aL1[q]);
+                        aR1[q] = fmaf(x2, hb.y, aR1[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NS; q++)
+                if (tb <= hi_q[q]) {
+                    dl[q] += g.x * aL0[q] + g.y * aL1[q];
+                    dr[q] += g.z * aR0[q] + g.w * aR1[q];
+                }
+        }
+    }
+    __syncthreads();  // (the caller may reuse the arrays)
+}
+
+// k_post's form of the same sum: a workgroup finishes four consecutive output blocks, one wave per block, four consecutive
+// frames per lane.  The tap index of (output sample r of block b, input sample m of source block tb) is
+// 256 (b - tb) + r - pd - m: it depends on the block DISTANCE delta = b - tb only, so the walk goes diagonal by diagonal -
+// for one delta every wave pairs its own block with the source block delta before it (four source blocks staged at once,
+// zero where the pairing is not one the reference cut: then nothing is added), all against ONE window of 511 taps.  All
+// four waves walk at once (walking source block by source block left three of them idle at the barriers: 6.6 ms per
+// 125 000-block batch at the shipped operating point, 3.4 ms with idle walks skipped, against this form's figure in
+// profiles/r3_shipped_defaults.md).  Four input samples per trip: the taps of a trip are two aligned 32-byte reads per
+// IR (the window is stored one entry late for that), the inputs one 16-byte broadcast read each, and the four taps a
+// lane holds rotate through registers without moves.
+// s_x: [4 waves][2 inputs][256] floats, s_h: [2 IRs][516] float2.
+__device__ __forceinline__ void tail_drop_tile4(const TailDrop& td, float* s_x, float2* s_h, int64_t b_tile, bool active, int64_t tabs0, int T,
+                                                int64_t pd, int64_t n_ref, const BlockParams* __restrict__ ptab, int pstride, int rc,
+                                                const float* __restrict__ cur1, const float* __restrict__ cur2, int pm, int64_t blo,
+                                                float (&dl)[4], float (&dr)[4]) {
+    constexpr int HW = 516;
+#pragma unroll
+    for (int q = 0; q < 4; q++) dl[q] = dr[q] = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nb = n_ref >> 8;
+    // block distances that can carry a cut term: the source block belongs to a call that started at or before tau - n_ref
+    // (delta >= n_ref / 256 - (pm - 1)), and some tap index 256 delta + r - pd - m lies in [0, L) (delta <= (L + pd + 254) / 256)
+    const int64_t d_lo = nb - (pm - 1), d_hi = ((int64_t)td.lmax + pd + 254) >> 8;
+    if (b_tile + 3 - d_lo < blo || b_tile + 3 < d_lo) return;  // (no source block old enough exists yet; uniform)
+    const int64_t b_own = b_tile + wave;
+    // last source block this wave's samples have lost: the blocks of every call that started at or before tau - n_ref
+    const int64_t v_own = (b_own << 8) - n_ref;
+    const int64_t hi_own = (active && v_own >= 0) ? ((v_own >> 8) / pm + 1) * pm - 1 : -1;
+    for (int64_t delta = d_lo; delta <= d_hi; delta++) {
+        __syncthreads();  // (the previous diagonal's samples and taps are no longer read)
+        // the four source blocks of this diagonal, 256 samples of both inputs each: thread i stages sample i of every one
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int64_t tb = b_tile + w - delta;
+            const int64_t vw = ((b_tile + w) << 8) - n_ref;
+            const int64_t hiw = vw >= 0 ? ((vw >> 8) / pm + 1) * pm - 1 : -1;
+            float x1 = 0.f, x2 = 0.f;
+            if (tb >= blo && tb >= 0 && tb <= hiw) {
+                const int64_t sig = (tb << 8) + tid;
+                if (tb >= tabs0) {
+                    x1 = cur1[sig - (tabs0 << 8)];
+                    x2 = cur2[sig - (tabs0 << 8)];
+                } else {
+                    x1 = td.xhist[(size_t)(sig & (td.xr - 1))];
+                    x2 = td.xhist[(size_t)td.xr + (sig & (td.xr - 1))];
+                }
+            }
+            s_x[(w * 2 + 0) * 256 + tid] = x1;
+            s_x[(w * 2 + 1) * 256 + tid] = x2;
+        }
+        const int64_t tb_own = b_own - delta;
+        const int64_t rel = tb_own - tabs0;
+        const int64_t kb = (delta << 8) - pd - 255;  // tap index of window entry 0 (stored at s_h[1])
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+            if (vi >= td.nv) break;
+            if (td.L0[vi] == 0 && td.L1[vi] == 0) continue;  // (uniform)
+            if (vi > 0) __syncthreads();  // (the previous voice's taps are no longer read)
+            for (int e = tid; e < HW; e += 256) {
+                const int64_t k = kb + e - 1;
+                s_h[e] = (k >= 0 && k < td.L0[vi]) ? td.h0[vi][k] : make_float2(0.f, 0.f);
+                s_h[HW + e] = (k >= 0 && k < td.L1[vi]) ? td.h1[vi][k] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tb_own >= 0 && tb_own >= blo && tb_own <= hi_own) {
+                if (rel >= 0 && rel < T) {
+                    const float* gv = ptab[rel * pstride].g[vi];
+                    g = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                } else {
+                    g = td.gring[(size_t)vi * rc + (size_t)(tb_own & (rc - 1))];
+                }
+            }
+            if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;  // (wave-uniform; the barriers are behind us)
+            // entry of (sample q, input sample m) = 4 lane + 255 + q - m, stored one later
+            const float2* ha = s_h + 4 * lane + 256;
+            const float2* hb = ha + HW;
+            const float* xa = s_x + (wave * 2 + 0) * 256;
+            const float* xb = xa + 256;
+            v2f a0[4], a1[4];  // {L, R} sums of the four samples: input 1, input 2
+#pragma unroll
+            for (int q = 0; q < 4; q++) a0[q] = a1[q] = v2f{0.f, 0.f};
+            v2f wa[4], wb[4];  // taps of samples q = 0..3 for the current input sample
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float2 ta = ha[q], tb2 = hb[q];
+                wa[q] = v2f{ta.x, ta.y};
+                wb[q] = v2f{tb2.x, tb2.y};
+            }
+            for (int m = 0; m < MC_B; m += 4) {
+                const float4 x1 = *reinterpret_cast<const float4*>(xa + m), x2 = *reinterpret_cast<const float4*>(xb + m);
+                // the four taps that come in during this trip: entries (4 lane + 255 - m) - 1 .. - 4, one aligned 32-byte run
+                const float4 na01 = *reinterpret_cast<const float4*>(ha - m - 4), na23 = *reinterpret_cast<const float4*>(ha - m - 2);
+                const float4 nb01 = *reinterpret_cast<const float4*>(hb - m - 4), nb23 = *reinterpret_cast<const float4*>(hb - m - 2);
+                const v2f n1a = v2f{na23.z, na23.w}, n2a = v2f{na23.x, na23.y}, n3a = v2f{na01.z, na01.w}, n4a = v2f{na01.x, na01.y};
+                const v2f n1b = v2f{nb23.z, nb23.w}, n2b = v2f{nb23.x, nb23.y}, n3b = v2f{nb01.z, nb01.w}, n4b = v2f{nb01.x, nb01.y};
+#define TD4_STEP(X1, X2, W0A, W1A, W2A, W3A, W0B, W1B, W2B, W3B)                 \
+    {                                                                            \
+        const v2f xx1 = v2f{X1, X1}, xx2 = v2f{X2, X2};                          \
+        a0[0] = __builtin_elementwise_fma(xx1, W0A, a0[0]);                      \
+        a0[1] = __builtin_elementwise_fma(xx1, W1A, a0[1]);                      \
+        a0[2] = __builtin_elementwise_fma(xx1, W2A, a0[2]);                      \
+        a0[3] = __builtin_elementwise_fma(xx1, W3A, a0[3]);                      \
+        a1[0] = __builtin_elementwise_fma(xx2, W0B, a1[0]);                      \
+        a1[1] = __builtin_elementwise_fma(xx2, W1B, a1[1]);                      \
+        a1[2] = __builtin_elementwise_fma(xx2, W2B, a1[2]);                      \
+        a1[3] = __builtin_elementwise_fma(xx2, W3B, a1[3]);                      \
+    }
+                TD4_STEP(x1.x, x2.x, wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]);
+                TD4_STEP(x1.y, x2.y, n1a, wa[0], wa[1], wa[2], n1b, wb[0], wb[1], wb[2]);
+                TD4_STEP(x1.z, x2.z, n2a, n1a, wa[0], wa[1], n2b, n1b, wb[0], wb[1]);
+                TD4_STEP(x1.w, x2.w, n3a, n2a, n1a, wa[0], n3b, n2b, n1b, wb[0]);
+#undef TD4_STEP
+                wa[3] = n1a, wa[2] = n2a, wa[1] = n3a, wa[0] = n4a;
+                wb[3] = n1b, wb[2] = n2b, wb[1] = n3b, wb[0] = n4b;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dl[q] += g.x * a0[q].x + g.y * a1[q].x;
+                dr[q] += g.z * a0[q].y + g.w * a1[q].y;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// JACK path: the Q8 terms of one period's PM x 256 samples into drop[2][PM * 256] ({L, R}).  They come from blocks at least
+// n_ref frames old, so the host launches this ahead of the period's tail kernel (in the shadow of the previous period, like
+// the sweep): off the critical path, and the tail kernels keep their register budget.  One workgroup of 256 threads.
+template <int PM>
+__global__ __launch_bounds__(256) void k_drop_period(TailDrop td, float* __restrict__ drop, int64_t tabs0, int64_t predelay, int64_t n_ref,
+                                                     int rc, int64_t blo) {
+    __shared__ float s_tdx[2 * 256];
+    __shared__ float2 s_tdh[2 * (PM * MC_B + 256)];
+    float dl[PM], dr[PM];
+    const int m = threadIdx.x;
+    tail_drop_tile<PM, MC_B, PM * MC_B>(td, s_tdx, s_tdh, tabs0 * MC_B, m, true, tabs0 * MC_B, 0, predelay, n_ref, nullptr, 0, rc, nullptr, nullptr, PM, blo,
+                                        tabs0 - 1, dl, dr);
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        drop[j * MC_B + m] = dl[j];
+        drop[PM * MC_B + j * MC_B + m] = dr[j];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K6: overlap-add + predelay + Q1/Q2 window sums + Q8 + saturating clamp + dry
 // mix (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,
@@ -1393,6 +1671,13 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     // pm = blocks per reference call (JACK period / 256): Q1/Q2/Q8 windows are measured from the call start
     // One wave per block, four consecutive frames per lane (16-byte loads and stores); grid = ceil(count / 4).
     const int tb = blockIdx.x * 4 + (threadIdx.x >> 6);  // block within the slice
+    float tdl[4] = {0.f, 0.f, 0.f, 0.f}, tdr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TD && td.on) {  // the Q8 terms of the workgroup's four blocks (1024 samples), cooperatively (tail_drop_tile)
+        __shared__ __attribute__((aligned(16))) float s_tdx[4 * 2 * 256];
+        __shared__ __attribute__((aligned(32))) float2 s_tdh[2 * 516];
+        tail_drop_tile4(td, s_tdx, s_tdh, tabs0 + first + (int64_t)blockIdx.x * 4, tb < count, tabs0, T, predelay, n_ref, ptab, pstride, rc, in1, in2,
+                        pm, ret.b0, tdl, tdr);
+    }
     if (tb < count) {
         const int t = first + tb, m0 = (threadIdx.x & 63) * 4;
         const int64_t i0 = (int64_t)t * MC_B + m0;
@@ -1490,10 +1775,8 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
             }
             float a = wl[k], b = wr_[k];
             if (TD && td.on) {  // input and gain history of the whole batch is in the rings already (k_fwd)
-                float dl, dr;
-                tail_drop(td, tau, tau0, T, predelay, n_ref, ptab, pstride, rc, in1, in2, dl, dr, pm, ret.b0, INT64_MAX);
-                a -= dl;
-                b -= dr;
+                a -= tdl[k];
+                b -= tdr[k];
             }
             const float vl = fminf(fmaxf((float)((double)a + cl), -1.f), 1.f);
             const float vr = fminf(fmaxf((float)((double)b + cr), -1.f), 1.f);
@@ -1635,6 +1918,7 @@ struct TailArgs {
     const unsigned long long* bell;
     unsigned* exited;
     unsigned long long park_ticks;
+    const float* drop;  // Q8 terms of the period's samples [2][256] (k_drop_period), or null
 };
 
 __device__ __forceinline__ void tail1_body(const TailArgs& A) {
@@ -1745,6 +2029,13 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
 
     s_tw[tid] = tw0;
     s_tw[tid + 256] = tw1;
+    // Q8: what the reference's cut at n_ref takes away from this period's samples comes from blocks at least n_ref frames
+    // old - nothing of it depends on the period itself: k_drop_period, launched ahead of this kernel, has summed it
+    float td_l[1] = {0.f}, td_r[1] = {0.f};
+    if (td.on) {
+        td_l[0] = A.drop[m];
+        td_r[0] = A.drop[MC_B + m];
+    }
     if (A.bell) {
         // Parked: everything above was requested without the period; only its 2 KB are still missing.  One lane
         // polls the mapped doorbell (a PCIe read per poll), the others wait at the barrier.
@@ -1919,10 +2210,8 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         }
         const float x1 = xin1, x2 = xin2;
         if (td.on) {
-            float dl, dr;
-            tail_drop(td, tau, tau0, 1, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, 1, ret.b0, INT64_MAX);
-            wl -= dl;
-            wr_ -= dr;
+            wl -= td_l[0];
+            wr_ -= td_r[0];
         }
         const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
@@ -2017,7 +2306,7 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
                                                float* __restrict__ outL, float* __restrict__ outR,
                                                const float2* __restrict__ g_tw, TailDrop td, uint2* __restrict__ fdl16,
                                                unsigned* __restrict__ done_flag, unsigned seq, Retired ret,
-                                               const unsigned long long* bell, unsigned* exited, unsigned long long park_ticks) {
+                                               const unsigned long long* bell, unsigned* exited, unsigned long long park_ticks, const float* __restrict__ drop) {
     // bell != null: launched one call ahead, parks on its doorbell like the single-block tail (tail1_body)
     static_assert(PM == 2 || PM == 4, "one wave per block of the call");
     __shared__ float2 s_tw[FFT_N];
@@ -2084,6 +2373,16 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
     }
     s_tw[tid] = tw0;
     s_tw[tid + 256] = tw1;
+    // Q8 terms of the call's PM x 256 samples: from blocks at least n_ref frames old, summed by k_drop_period ahead of this kernel
+    float td_l[PM], td_r[PM];
+#pragma unroll
+    for (int j = 0; j < PM; j++) {
+        td_l[j] = td_r[j] = 0.f;
+        if (td.on) {
+            td_l[j] = drop[j * MC_B + m];
+            td_r[j] = drop[PM * MC_B + j * MC_B + m];
+        }
+    }
     if (bell) {
         // Parked: everything above was requested without the period; only its samples are still missing.  One lane polls
         // the doorbell, the others wait at the barrier.
@@ -2300,10 +2599,8 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
         }
         const float x1 = xin[j][0], x2 = xin[j][1];
         if (td.on) {
-            float dl, dr;
-            tail_drop(td, tau, tau0, PM, predelay, n_ref, ptab, 0, rc, s_in[0], s_in[1], dl, dr, PM, ret.b0, INT64_MAX);
-            wl -= dl;
-            wr_ -= dr;
+            wl -= td_l[j];
+            wr_ -= td_r[j];
         }
         const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);

@@ -245,6 +245,7 @@ struct mc_engine {
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
     float4* d_part_jack[2] = {nullptr, nullptr};  // JACK path: the sweep's partials, double-buffered by block parity
+    float* d_drop[2] = {nullptr, nullptr};        // JACK path, Q8 regime: a period's tail-drop terms [2][1024] (k_drop_period), by period parity
     JackPre pre;                     // the period parked one call ahead
     bool park = true;                // MCCONV_NO_PARK=1: every period launched when it arrives
     unsigned long long park_ticks = 10000000ull;  // a parked tail gives up after this many 100 MHz ticks (100 ms; MCCONV_PARK_MS)
@@ -774,6 +775,21 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
     td.xr = e->xr;
     td.gring = e->d_gring;
     return td;
+}
+
+// JACK path in the Q8 regime: the tail-drop terms of the period that starts at block blk (pm blocks), ahead of its tail kernel
+// on the engine's stream (they depend on blocks at least n_ref frames old only).  Returns the buffer the tail reads, or null.
+const float* launch_drop_period(mc_engine* e, const TailDrop& td, uint64_t blk, uint64_t predelay) {
+    if (!td.on) return nullptr;
+    float* dst = e->d_drop[(blk / (uint64_t)e->pm) & 1];
+    const int64_t blo = (int64_t)e->epoch_b0;
+    if (e->pm == 1)
+        hipLaunchKernelGGL(k_drop_period<1>, dim3(1), dim3(256), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, e->rc, blo);
+    else if (e->pm == 2)
+        hipLaunchKernelGGL(k_drop_period<2>, dim3(1), dim3(256), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, e->rc, blo);
+    else
+        hipLaunchKernelGGL(k_drop_period<4>, dim3(1), dim3(256), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, e->rc, blo);
+    return dst;
 }
 
 // shard of a voice's partition range [p_begin, p_end), multiples of 16
@@ -1784,6 +1800,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
         A.exited = e->hd_exited;
         A.park_ticks = e->park_ticks;
+        A.drop = launch_drop_period(e, A.td, blk, st.ctx.predelay);  // (queued ahead of the tail this argument block is for)
         return A;
     };
 
@@ -2201,13 +2218,15 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     auto launch_tail = [&](const Staged& st, const PPlan& pl, uint64_t blk, unsigned seq, bool parked) {
         const int slot0 = (int)(blk & (uint64_t)(e->ring - 1));
         const unsigned long long* bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
+        const TailDrop tdp = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
+        const float* drop = launch_drop_period(e, tdp, blk, st.ctx.predelay);
 #define MC_LAUNCH_TAILP(PM)                                                                                                  \
     hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, pin1, pin2, pl.vset, e->Pstride, e->d_fdl, e->d_slotgain, \
                        e->ring, slot0, e->d_part, pl.nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr, e->d_cring, e->rc,    \
                        st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)blk, (int64_t)st.ctx.predelay,     \
                        (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,                                \
-                       make_taildrop(e, st.ctx.vir, st.ctx.predelay), e->d_fdl16, e->hd_flag, seq, make_retired(e), bell,     \
-                       e->hd_exited, e->park_ticks)
+                       tdp, e->d_fdl16, e->hd_flag, seq, make_retired(e), bell,     \
+                       e->hd_exited, e->park_ticks, drop)
         if (pm == 2)
             MC_LAUNCH_TAILP(2);
         else
@@ -2532,6 +2551,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     }
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) ENG_TRY(hipMalloc(&e->d_part_jack[i], sizeof(float4) * (size_t)MC_NB * e->nchunk * MC_MAXV));
+    for (int i = 0; i < 2; i++) ENG_TRY(hipMalloc(&e->d_drop[i], sizeof(float) * 2 * 4 * MC_B));
     if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
@@ -2658,6 +2678,8 @@ void mc_destroy(mc_engine* e) {
     if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
     (void)hipFree(e->d_part_jack[0]);
     (void)hipFree(e->d_part_jack[1]);
+    (void)hipFree(e->d_drop[0]);
+    (void)hipFree(e->d_drop[1]);
     if (e->kev_created)
         for (int i = 0; i < kEvPool; i++) {
             (void)hipEventDestroy(e->kev[i][0]);
