@@ -1048,7 +1048,7 @@ def main():
             fused = lv == 254
             cb = second_level_bytes(blk, int(ks["partitions"]), fused)
             gbs = cb["total"] / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-            tr = labelled_profile("r2_hbm_traffic.json", "headline")
+            tr = labelled_profile("r3_hbm_traffic.json", "headline")
             traffic = None
             if tr:
                 rec = [v for k, v in tr["data"].items() if ("k_g2_mac" if fused else "k_f2_") in k]
@@ -1062,7 +1062,7 @@ def main():
             roofline["algorithmic_bytes"] = cb
             if tr:
                 roofline["traffic_source"] = {k: tr[k] for k in ("from", "commit", "note")}
-            bind = labelled_profile("r2_headline_counters.json", "derived") if fused else None
+            bind = labelled_profile("r3_headline_counters.json", "derived") if fused else None
             if bind:
                 roofline["binding_resource"] = bind
             # the whole step against the same roof: the other launches of a step are pure streams (forward transforms:

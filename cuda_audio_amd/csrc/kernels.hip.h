@@ -3726,7 +3726,7 @@ __global__ __launch_bounds__(G2D_THREADS, 4) void k_g2_duo(const float4* __restr
     // solo (measurement, MCCONV_G2_DUO_SOLO=1): group 0 takes every item, group 1 only keeps the barriers company
     const int lane8 = blockIdx.x & 7, wpl = (int)(gridDim.x >> 3) * (solo ? 1 : 2), jw = (int)(blockIdx.x >> 3) * (solo ? 1 : 2);
 #if G2_STAMPS
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0, st_now;
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_now;
     int st_items = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #define G2D_STAMP(k)                                                                   \
@@ -3772,11 +3772,14 @@ __global__ __launch_bounds__(G2D_THREADS, 4) void k_g2_duo(const float4* __restr
                     if (n < L) x[r] = fk[(sb + n) & (ring - 1)];
                 }
                 g2d_bars(G2D_NB - 1);  // (the other group's inverse transforms run meanwhile)
+                G2D_STAMP(4);  // F, part 1: the loads issued + the other group's first four segments
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) {
                     x1[r] = v2f{x[r].x, cj * x[r].y};
                     x2[r] = v2f{x[r].z, cj * x[r].w};
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                G2D_STAMP(5);  // F, part 2: what the loads still needed after that
             }
             g2d_bar();
             G2D_STAMP(0);
@@ -3915,9 +3918,9 @@ __global__ __launch_bounds__(G2D_THREADS, 4) void k_g2_duo(const float4* __restr
     if ((threadIdx.x & 511) == 0 && (blockIdx.x == 3 || blockIdx.x == 137 || blockIdx.x == 200))
     {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - st_t0, dr = __builtin_amdgcn_s_memrealtime() - st_r0;
-        printf("g2 wg %d grp %d items %d: F %llu C12 %llu P %llu C34 %llu (cycles per item); workgroup %llu cycles in %llu x 10 ns = %.0f MHz\n",
-               (int)blockIdx.x, grp, st_items, st_acc[0] / st_items, st_acc[1] / st_items, st_acc[2] / st_items, st_acc[3] / st_items,
-               dt, dr, (double)dt / (double)dr * 100.0);
+        printf("g2 wg %d grp %d items %d: F %llu (= to the 4th barrier %llu + loads still out %llu + last barrier %llu) C12 %llu P %llu C34 %llu (cycles per item); workgroup %llu cycles in %llu x 10 ns = %.0f MHz\n",
+               (int)blockIdx.x, grp, st_items, (st_acc[0] + st_acc[4] + st_acc[5]) / st_items, st_acc[4] / st_items, st_acc[5] / st_items, st_acc[0] / st_items,
+               st_acc[1] / st_items, st_acc[2] / st_items, st_acc[3] / st_items, dt, dr, (double)dt / (double)dr * 100.0);
     }
 #endif
 }
