@@ -1919,6 +1919,13 @@ struct TailArgs {
     unsigned* exited;
     unsigned long long park_ticks;
     const float* drop;  // Q8 terms of the period's samples [2][256] (k_drop_period), or null
+    // Tagged I/O (round 3, MCCONV_TAGGED_IO): the period and the output travel as 8-byte granules {value, sequence number}.  A
+    // parked tail polls the period's own granules (every lane its two) instead of a doorbell followed by a second round trip
+    // for the 2 KB it announces, and the host polls the output's granules instead of a completion word that has to wait behind
+    // a system-scope release of every store of the kernel.  in_gran: [2][256] in device memory the CPU writes through the BAR
+    // (used only when `bell` is set); out_gran: [2][256] in mapped host memory (null: plain outL / outR + completion word).
+    const unsigned long long* in_gran;
+    unsigned long long* out_gran;
 };
 
 __device__ __forceinline__ void tail1_body(const TailArgs& A) {
@@ -2036,7 +2043,40 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         td_l[0] = A.drop[m];
         td_r[0] = A.drop[MC_B + m];
     }
-    if (A.bell) {
+    float xin1 = 0.f, xin2 = 0.f;
+    bool have_in = false;
+    if (A.bell && A.in_gran) {
+        // Parked, tagged input: every lane polls its own two granules of the period; wave 0 also watches the doorbell word for
+        // the "give up" command and the park time.  A wave leaves the loop when all its lanes hold this period's samples, or
+        // when wave 0 has said to leave (an LDS word); the barrier behind the loop makes the decision the workgroup's.
+        __shared__ int s_abort;
+        if (tid == 0) s_abort = 0;
+        __syncthreads();
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned long long g1 = __hip_atomic_load(A.in_gran + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long g2 = __hip_atomic_load(A.in_gran + MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (__all((unsigned)(g1 >> 32) == seq && (unsigned)(g2 >> 32) == seq)) {
+                xin1 = __uint_as_float((unsigned)g1);
+                xin2 = __uint_as_float((unsigned)g2);
+                break;
+            }
+            if (tid == 0) {
+                const unsigned long long v = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)v == seq && (v >> 32) != 0) {
+                    *(volatile int*)&s_abort = 1;  // told to give up
+                } else if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {
+                    __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    *(volatile int*)&s_abort = 1;  // the host has been away for longer than the park time
+                }
+            }
+            if (*(volatile int*)&s_abort) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        if (*(volatile int*)&s_abort) return;  // nothing has been written: the host launches this period again
+        have_in = true;
+    } else if (A.bell) {
         // Parked: everything above was requested without the period; only its 2 KB are still missing.  One lane
         // polls the mapped doorbell (a PCIe read per poll), the others wait at the barrier.
         __shared__ int s_go;
@@ -2066,8 +2106,10 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
     // (system scope: the period may sit in device memory the CPU wrote through the BAR - not to be served from a cache)
-    const float xin1 = __hip_atomic_load(in1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const float xin2 = __hip_atomic_load(in2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!have_in) {
+        xin1 = __hip_atomic_load(in1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        xin2 = __hip_atomic_load(in2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     s_in[0][tid] = xin1;
     s_in[1][tid] = xin2;
     __syncthreads();
@@ -2215,8 +2257,14 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         }
         const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
-        outL[m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
-        outR[m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+        const float yl = vl + x1 * bp.d[0] + x2 * bp.d[1], yr = vr + x1 * bp.d[2] + x2 * bp.d[3];
+        if (A.out_gran) {  // the output as granules {value, sequence number}: on the host as soon as the posted writes land
+            __hip_atomic_store(A.out_gran + m, ((unsigned long long)seq << 32) | __float_as_uint(yl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(A.out_gran + MC_B + m, ((unsigned long long)seq << 32) | __float_as_uint(yr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            outL[m] = yl;
+            outR[m] = yr;
+        }
         write_history(td, tau, tabs0, m, x1, x2, bp, rc);
     }
     // the state later periods need: delay-line slot, slot gains, segments, wet ring, Q1/Q2 prefix entry
@@ -2244,7 +2292,12 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         }
     }
     // publish completion to the host (mapped pinned memory): all waves drain their stores at the barrier
-    // (__syncthreads waits vmcnt(0)), then ONE lane issues the system-scope release and the sequence number
+    // (__syncthreads waits vmcnt(0)), then ONE lane issues the system-scope release and the sequence number.
+    // With tagged output the host does not look at the word (the granules are the completion): no release, the kernel ends
+    // 0.6 us earlier and the next period's kernel starts that much sooner (back-to-back calls).
+#ifndef MC_JACK_TRACE
+    if (A.out_gran) return;
+#endif
     __syncthreads();
     if (tid == 0) {
 #ifdef MC_JACK_TRACE
@@ -2306,7 +2359,8 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
                                                float* __restrict__ outL, float* __restrict__ outR,
                                                const float2* __restrict__ g_tw, TailDrop td, uint2* __restrict__ fdl16,
                                                unsigned* __restrict__ done_flag, unsigned seq, Retired ret,
-                                               const unsigned long long* bell, unsigned* exited, unsigned long long park_ticks, const float* __restrict__ drop) {
+                                               const unsigned long long* bell, unsigned* exited, unsigned long long park_ticks, const float* __restrict__ drop,
+                                               const unsigned long long* in_gran, unsigned long long* out_gran) {
     // bell != null: launched one call ahead, parks on its doorbell like the single-block tail (tail1_body)
     static_assert(PM == 2 || PM == 4, "one wave per block of the call");
     __shared__ float2 s_tw[FFT_N];
@@ -2383,7 +2437,39 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
             td_r[j] = drop[PM * MC_B + j * MC_B + m];
         }
     }
-    if (bell) {
+    if (bell && in_gran) {
+        // Parked, tagged input (see k_tail1): every lane polls its own 2 PM granules of the period, wave 0 watches the doorbell word
+        // for the "give up" command and the park time
+        __shared__ int s_abort;
+        if (tid == 0) s_abort = 0;
+        __syncthreads();
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < PM; j++) {
+                const unsigned long long g1 = __hip_atomic_load(in_gran + j * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long g2 = __hip_atomic_load(in_gran + (PM + j) * MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = ok && (unsigned)(g1 >> 32) == seq && (unsigned)(g2 >> 32) == seq;
+                xin[j][0] = __uint_as_float((unsigned)g1);
+                xin[j][1] = __uint_as_float((unsigned)g2);
+            }
+            if (__all(ok)) break;
+            if (tid == 0) {
+                const unsigned long long v = __hip_atomic_load(bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)v == seq && (v >> 32) != 0) {
+                    *(volatile int*)&s_abort = 1;
+                } else if (__builtin_amdgcn_s_memrealtime() - t0 > park_ticks) {
+                    __hip_atomic_store(exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    *(volatile int*)&s_abort = 1;
+                }
+            }
+            if (*(volatile int*)&s_abort) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        if (*(volatile int*)&s_abort) return;  // nothing has been written: the host launches this period again
+    } else if (bell) {
         // Parked: everything above was requested without the period; only its samples are still missing.  One lane polls
         // the doorbell, the others wait at the barrier.
         __shared__ int s_go;
@@ -2604,8 +2690,15 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
         }
         const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
         const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
-        outL[j * MC_B + m] = vl + x1 * bp.d[0] + x2 * bp.d[1];
-        outR[j * MC_B + m] = vr + x1 * bp.d[2] + x2 * bp.d[3];
+        const float yl = vl + x1 * bp.d[0] + x2 * bp.d[1], yr = vr + x1 * bp.d[2] + x2 * bp.d[3];
+        if (out_gran) {  // granules {value, sequence number}: on the host as soon as the posted writes land (see k_tail1)
+            __hip_atomic_store(out_gran + j * MC_B + m, ((unsigned long long)seq << 32) | __float_as_uint(yl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(out_gran + (PM + j) * MC_B + m, ((unsigned long long)seq << 32) | __float_as_uint(yr), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            outL[j * MC_B + m] = yl;
+            outR[j * MC_B + m] = yr;
+        }
     }
     // ---- state for later periods (no global store before this point: see k_tail1) ----
 #pragma unroll

@@ -256,6 +256,12 @@ struct mc_engine {
     // (MCCONV_BAR_IO=0: mapped host memory as before).  16 floats = the doorbell's line, then in1, in2 (room for 1024 frames each).
     float* d_bar = nullptr;
     bool bar_io = false;
+    // Tagged I/O of the 256-frame JACK path (TailArgs::in_gran / out_gran): input granules at byte 16384 of d_bar, output granules
+    // in mapped host memory.  On where the BAR path is (MCCONV_TAGGED_IO=0: doorbell + completion word as in round 2).
+    bool tio = false;
+    bool tio_long = false;  // ... also for 512 / 1024-frame periods (MCCONV_TAGGED_IO=2; measured slower there: twice the bytes over the link)
+    unsigned long long* h_gran = nullptr;   // [2][256] output granules {value, sequence number}
+    unsigned long long* hd_gran = nullptr;
     bool host_out_direct = true;  // MCCONV_HOST_OUT_DIRECT=0: pinned-buffer batches copy their output out instead of storing it to the host
     unsigned* h_exited = nullptr;                 // mapped: sequence number of a parked tail that gave up on its own
     unsigned* hd_exited = nullptr;
@@ -1642,6 +1648,33 @@ int wait_period(mc_engine* e, unsigned seq) {
     return MC_OK;
 }
 
+// Tagged output (mc_engine::tio): the period's 512 output granules carry its sequence number; they are on the host when every
+// tag matches.  Same return values as wait_period.
+int wait_period_tagged(mc_engine* e, unsigned seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    const int ngran = 2 * e->pm * MC_B;
+    int first_missing = ngran - 1;  // (stores mostly arrive in order: watch the last one, then check them all)
+    for (;;) {
+        if ((unsigned)(__atomic_load_n(e->h_gran + first_missing, __ATOMIC_ACQUIRE) >> 32) == seq) {
+            int i = 0;
+            while (i < ngran && (unsigned)(__atomic_load_n(e->h_gran + i, __ATOMIC_ACQUIRE) >> 32) == seq) i++;
+            if (i == ngran) return MC_OK;
+            first_missing = i;
+            continue;
+        }
+        if (__atomic_load_n(e->h_exited, __ATOMIC_ACQUIRE) == seq) return 1;
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(300)) {
+            unpark(e);
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            for (int i = 0; i < ngran; i++)
+                if ((unsigned)(__atomic_load_n(e->h_gran + i, __ATOMIC_ACQUIRE) >> 32) != seq) return fail(MC_ERR_HIP, "period did not complete");
+            return MC_OK;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 // One JACK period with host buffers (Convolution::onProcess, conv.cu:287-466): zero-copy I/O through mapped pinned
 // memory, the streaming MAC over the partitions that do not depend on the new block, and the fused k_tail1.
 //
@@ -1667,14 +1700,16 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     const auto tr0 = std::chrono::steady_clock::now();
 #endif
     const size_t cap = (size_t)e->Thost * MC_B;
-    if (e->bar_io) {
-        std::memcpy(e->d_bar + 16, in1, sizeof(float) * MC_B);
-        std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, sizeof(float) * MC_B);
-        _mm_sfence();  // (write-combined stores: out of the buffers before a doorbell or a launch can refer to them)
-    } else {
-        std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
-        std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
-    }
+    auto copy_period_in = [&]() {  // the period where a tail launched now reads it
+        if (e->bar_io) {
+            std::memcpy(e->d_bar + 16, in1, sizeof(float) * MC_B);
+            std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, sizeof(float) * MC_B);
+            _mm_sfence();  // (write-combined stores: out of the buffers before a doorbell or a launch can refer to them)
+        } else {
+            std::memcpy(e->h_io + 0 * cap, in1, sizeof(float) * MC_B);
+            std::memcpy(e->h_io + 1 * cap, in2, sizeof(float) * MC_B);
+        }
+    };
     mc_cc_value cc[2];
     {
         int rc = sample_params(e, cc);
@@ -1801,6 +1836,8 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.exited = e->hd_exited;
         A.park_ticks = e->park_ticks;
         A.drop = launch_drop_period(e, A.td, blk, st.ctx.predelay);  // (queued ahead of the tail this argument block is for)
+        A.in_gran = e->tio ? reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(e->d_bar) + 16384) : nullptr;
+        A.out_gran = e->tio ? e->hd_gran : nullptr;
         return A;
     };
 
@@ -1817,7 +1854,23 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                      same_cc(cc[1], e->pre.cc[1]) && cc[0].predelay == e->cur_delay;
     if (hit) {
         my_seq = e->pre.seq;
-        ring_bell(e, my_seq, 0);
+        if (e->tio) {
+            // tagged input: the period as granules {sample, sequence number} straight into device memory - every lane of the
+            // parked tail is polling its own two; no doorbell, no second round trip for the data it would announce
+            volatile unsigned long long* g = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(e->d_bar) + 16384);
+            const unsigned long long tag = (unsigned long long)my_seq << 32;
+            for (int i = 0; i < MC_B; i++) {
+                uint32_t a, b;
+                std::memcpy(&a, in1 + i, 4);
+                std::memcpy(&b, in2 + i, 4);
+                g[i] = tag | a;
+                g[MC_B + i] = tag | b;
+            }
+            _mm_sfence();
+        } else {
+            copy_period_in();
+            ring_bell(e, my_seq, 0);
+        }
         e->pre.valid = false;
         e->n_park_hit++;
         st_now = e->pre.st;
@@ -1835,6 +1888,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         }
     } else {
         unpark(e);
+        copy_period_in();
         {
             int rc = drain_post(e);
             if (!rc) rc = retire_epoch(e, cc[0].predelay);
@@ -1938,7 +1992,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
     // the output of THIS block is on the host once its tail has published its sequence number.  Spin on the mapped word
     // (a JACK callback blocks here anyway; the reference blocks in cudaEventSynchronize, conv.cu:455).
     for (;;) {
-        int rc = wait_period(e, my_seq);
+        int rc = e->tio ? wait_period_tagged(e, my_seq) : wait_period(e, my_seq);
         if (rc == MC_OK) break;
         if (rc != 1) return rc;
         // the parked tail gave up on its own (the host was away for more than park_ms): the same period, launched the
@@ -1947,6 +2001,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         relaunch_ok = false;
         e->n_park_timeout++;
         unpark(e);  // (the kernel parked for the period after this one must not run before it)
+        copy_period_in();  // (a tail launched now reads the plain copy of the period)
         // That kernel (launched above, behind a tail that had already left the stream) ran at once: the sweep it carries - the
         // one of the period after next - went into the partial-sum buffer of THIS period (same parity) and read a delay line
         // without this period's block.  unpark() has forgotten it; this period's own partial sums are summed again, on the
@@ -1962,8 +2017,16 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
 #ifdef MC_JACK_TRACE
     const auto tr2 = std::chrono::steady_clock::now();
 #endif
-    std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
-    std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * MC_B);
+    if (e->tio) {
+        for (int i = 0; i < MC_B; i++) {
+            const uint32_t a = (uint32_t)e->h_gran[i], b = (uint32_t)e->h_gran[MC_B + i];
+            std::memcpy(outL + i, &a, 4);
+            std::memcpy(outR + i, &b, 4);
+        }
+    } else {
+        std::memcpy(outL, e->h_io + 2 * cap, sizeof(float) * MC_B);
+        std::memcpy(outR, e->h_io + 3 * cap, sizeof(float) * MC_B);
+    }
 #ifdef MC_JACK_TRACE
     {
         const auto tr3 = std::chrono::steady_clock::now();
@@ -2124,18 +2187,19 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     if (e->pipe_count) return fail(MC_ERR_STATE, "a sharded batch is still pending");
     if (e->sliced) return fail(MC_ERR_STATE, "single-period call on a block-sliced engine (mc_reset first)");
     const int pm = e->pm;
+    const bool tio_p = e->tio && e->tio_long;  // tagged I/O pays for 256-frame periods only (see mc_engine::tio_long)
     const size_t bytes = (size_t)pm * MC_B * sizeof(float), cap = (size_t)e->Thost * MC_B;
-    const float *pin1 = e->hd_io + 0 * cap, *pin2 = e->hd_io + 1 * cap;
-    if (e->bar_io) {  // the period straight into device memory through the BAR (see mc_engine::d_bar)
-        std::memcpy(e->d_bar + 16, in1, bytes);
-        std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, bytes);
-        _mm_sfence();
-        pin1 = e->d_bar + 16;
-        pin2 = e->d_bar + 16 + 4 * MC_B;
-    } else {
-        std::memcpy(e->h_io + 0 * cap, in1, bytes);
-        std::memcpy(e->h_io + 1 * cap, in2, bytes);
-    }
+    const float *pin1 = e->bar_io ? e->d_bar + 16 : e->hd_io + 0 * cap, *pin2 = e->bar_io ? e->d_bar + 16 + 4 * MC_B : e->hd_io + 1 * cap;
+    auto copy_period_in = [&]() {  // the period where a tail launched now reads it
+        if (e->bar_io) {  // straight into device memory through the BAR (see mc_engine::d_bar)
+            std::memcpy(e->d_bar + 16, in1, bytes);
+            std::memcpy(e->d_bar + 16 + 4 * MC_B, in2, bytes);
+            _mm_sfence();
+        } else {
+            std::memcpy(e->h_io + 0 * cap, in1, bytes);
+            std::memcpy(e->h_io + 1 * cap, in2, bytes);
+        }
+    };
     mc_cc_value cc[2];
     {
         int rc = sample_params(e, cc);
@@ -2226,7 +2290,9 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
                        st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)blk, (int64_t)st.ctx.predelay,     \
                        (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,                                \
                        tdp, e->d_fdl16, e->hd_flag, seq, make_retired(e), bell,     \
-                       e->hd_exited, e->park_ticks, drop)
+                       e->hd_exited, e->park_ticks, drop,                            \
+                       tio_p ? reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(e->d_bar) + 16384) : nullptr, \
+                       tio_p ? e->hd_gran : nullptr)
         if (pm == 2)
             MC_LAUNCH_TAILP(2);
         else
@@ -2247,7 +2313,22 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
                      same_cc(cc[1], e->pre.cc[1]) && cc[0].predelay == e->cur_delay;
     if (hit) {
         my_seq = e->pre.seq;
-        ring_bell(e, my_seq, 0);
+        if (tio_p) {  // tagged input (see process_one): granules [2][pm * 256] {sample, sequence number}, no doorbell
+            volatile unsigned long long* g = reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(e->d_bar) + 16384);
+            const unsigned long long tag = (unsigned long long)my_seq << 32;
+            const int n = pm * MC_B;
+            for (int i = 0; i < n; i++) {
+                uint32_t a, b;
+                std::memcpy(&a, in1 + i, 4);
+                std::memcpy(&b, in2 + i, 4);
+                g[i] = tag | a;
+                g[n + i] = tag | b;
+            }
+            _mm_sfence();
+        } else {
+            copy_period_in();
+            ring_bell(e, my_seq, 0);
+        }
         e->pre.valid = false;
         e->n_park_hit++;
         st = e->pre.st;
@@ -2257,6 +2338,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     } else {
         int rc = drain_post(e);
         if (!rc) rc = leave_jack_path(e);
+        copy_period_in();
         if (!rc) rc = retire_epoch(e, cc[0].predelay);
         if (!rc) rc = stage_params(e, pm, cc, &st);
         if (rc) return rc;
@@ -2310,9 +2392,10 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         }
     }
     for (;;) {
-        int rc = wait_period(e, my_seq);
+        int rc = tio_p ? wait_period_tagged(e, my_seq) : wait_period(e, my_seq);
         if (rc == MC_OK) break;
         if (rc != 1) return rc;
+        copy_period_in();  // (a tail launched now reads the plain copy of the period)
         // the parked tail gave up on its own (the host was away for more than park_ms): the same period the ordinary way.
         // What was queued behind it worked on a delay line without this period: the next period's parked tail is told to
         // give up, its sweep is forgotten, and this period's own partial sums are summed again (the sweep behind overwrote them)
@@ -2327,8 +2410,17 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         launch_tail(st, pl, e->t_front - (uint64_t)pm, my_seq, false);
         HIP_TRY(hipGetLastError());
     }
-    std::memcpy(outL, e->h_io + 2 * cap, bytes);
-    std::memcpy(outR, e->h_io + 3 * cap, bytes);
+    if (tio_p) {
+        const int n = pm * MC_B;
+        for (int i = 0; i < n; i++) {
+            const uint32_t a = (uint32_t)e->h_gran[i], b = (uint32_t)e->h_gran[n + i];
+            std::memcpy(outL + i, &a, 4);
+            std::memcpy(outR + i, &b, 4);
+        }
+    } else {
+        std::memcpy(outL, e->h_io + 2 * cap, bytes);
+        std::memcpy(outR, e->h_io + 3 * cap, bytes);
+    }
     return MC_OK;
 }
 
@@ -2458,8 +2550,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
             int large_bar = 0;
             const char* bi = std::getenv("MCCONV_BAR_IO");
             if ((!bi || std::atoi(bi) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large_bar &&
-                hipExtMallocWithFlags((void**)&e->d_bar, 16384, hipDeviceMallocFinegrained) == hipSuccess) {
-                ENG_TRY(hipMemset(e->d_bar, 0, 16384));
+                hipExtMallocWithFlags((void**)&e->d_bar, 32768, hipDeviceMallocFinegrained) == hipSuccess) {
+                ENG_TRY(hipMemset(e->d_bar, 0, 32768));
                 e->bar_io = true;
             } else {
                 (void)hipGetLastError();
@@ -2533,8 +2625,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         int large_bar = 0;
         const char* bi = std::getenv("MCCONV_BAR_IO");
         if ((!bi || std::atoi(bi) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large_bar &&
-            hipExtMallocWithFlags((void**)&e->d_bar, 16384, hipDeviceMallocFinegrained) == hipSuccess) {
-            ENG_TRY(hipMemset(e->d_bar, 0, 16384));
+            hipExtMallocWithFlags((void**)&e->d_bar, 32768, hipDeviceMallocFinegrained) == hipSuccess) {
+            ENG_TRY(hipMemset(e->d_bar, 0, 32768));
             e->bar_io = true;
         } else {
             (void)hipGetLastError();
@@ -2545,6 +2637,13 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_done_ctr, sizeof(unsigned)));
     ENG_TRY(hipMemset(e->d_done_ctr, 0, sizeof(unsigned)));
     if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
+    if (e->bar_io && e->spin_wait && !(std::getenv("MCCONV_TAGGED_IO") && std::atoi(std::getenv("MCCONV_TAGGED_IO")) == 0)) {
+        ENG_TRY(hipHostMalloc(&e->h_gran, sizeof(unsigned long long) * 2 * 4 * MC_B, hipHostMallocMapped));  // (room for a 1024-frame period)
+        ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_gran, e->h_gran, 0));
+        std::memset(e->h_gran, 0, sizeof(unsigned long long) * 2 * 4 * MC_B);
+        e->tio = true;
+        e->tio_long = std::getenv("MCCONV_TAGGED_IO") && std::atoi(std::getenv("MCCONV_TAGGED_IO")) == 2;
+    }
     for (int i = 0; i < kStageBufs; i++) {
         ENG_TRY(hipHostMalloc(&e->h_ptab[i], sizeof(BlockParams) * (size_t)e->Tmax, hipHostMallocDefault));
         ENG_TRY(hipEventCreateWithFlags(&e->ptab_ev[i], hipEventDisableTiming));
@@ -2667,6 +2766,7 @@ void mc_destroy(mc_engine* e) {
     if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
     if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
     if (e->d_bar) (void)hipFree(e->d_bar);
+    if (e->h_gran) (void)hipHostFree(e->h_gran);
     if (e->h_io) (void)hipHostFree(e->h_io);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     for (int i = 0; i < kStageBufs; i++) {

