@@ -609,7 +609,7 @@ def main():
                 # single-transform restatement of conv.cu does - from a cold start, a fresh engine, one batch of 160 blocks
                 import oracle
 
-                nchk = 160
+                nchk = a.fft_size // BLOCK + 160  # (the cut terms start n_ref frames into the stream: 160 blocks with them)
                 e2 = Pairs(a, local, 1, nchk)
                 x = xs[0]
                 got = e2[0].process(x[0, :nchk * BLOCK], x[1, :nchk * BLOCK])
@@ -626,7 +626,8 @@ def main():
                 res["parity"] = {"rms_err": err, "rms_signal": float(np.sqrt(np.mean(want * want))), "blocks": nchk, "tolerance": RMS_TOL,
                                  "ok": bool(err <= RMS_TOL),
                                  "oracle": "oracle/oracle.c orc_ref_process (float64 restatement of conv.cu:287-466 with the reference's own "
-                                           "buffers: the Q8 tail drop comes out of the restated code), cold start, a fresh engine, one batch"}
+                                           "buffers: the Q8 tail drop comes out of the restated code), cold start, a fresh engine, one batch that runs "
+                                           "160 blocks past the point (n_ref frames in) where the cut terms begin"}
             elif T < reach + 64 or before < 400:
                 res["parity"] = {"skipped": f"steady-state excerpt needs batches of >= {reach + 64} blocks and a settled cross-fade"}
             else:
@@ -1060,9 +1061,10 @@ def main():
                              "kernel": "k_g2_mac" if fused else "k_f2_fwd + k_f2_prod"}, **common)
             roofline["algorithmic_bytes_per_launch"] = cb["total"]
             roofline["algorithmic_bytes"] = cb
-            if tr:
+            # numbers copied from the committed headline profile are attached only when this run's launch is the profiled one
+            if tr and traffic is not None:
                 roofline["traffic_source"] = {k: tr[k] for k in ("from", "commit", "note")}
-            bind = labelled_profile("r3_headline_counters.json", "derived") if fused else None
+            bind = labelled_profile("r3_headline_counters.json", "derived") if fused and traffic is not None else None
             if bind:
                 roofline["binding_resource"] = bind
             # the whole step against the same roof: the other launches of a step are pure streams (forward transforms:

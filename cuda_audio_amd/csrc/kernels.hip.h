@@ -1288,6 +1288,17 @@ struct TailDrop {
     float* xhist;   // [2][xr] input history ring (absolute sample index mod xr)
     int xr;
     float4* gring;  // [MC_MAXV][rc] wet gains of past blocks
+    // frequency-domain form of the same terms (tail_drop_fft, k_post): the voices' partition spectra, the delay line and
+    // its slot gains (both indexed by absolute block mod ring), the transform's twiddles; fft != 0: use it
+    int fft;
+    const float4* H0s[MC_MAXV];  // [256 bins][pstride_ir] {H_L, H_R} of voice v's IR for input 1
+    const float4* H1s[MC_MAXV];  // ... for input 2
+    int P0[MC_MAXV], P1[MC_MAXV];
+    int pstride_ir;
+    const float4* fdl;
+    const float4* slotgain;
+    int ring;
+    const float2* g_tw;
 };
 
 __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
@@ -1491,6 +1502,110 @@ __device__ __forceinline__ void tail_drop_tile(const TailDrop& td, float* s_x, f
     __syncthreads();  // (the caller may reuse the arrays)
 }
 
+// The same terms in the frequency domain (k_post, one wave per output block; round 3).  Block t's contribution at lag s from
+// its start is sum_p seg_{t,p}[s - 256 p], seg_{t,p} = IFFT512(X_t H_p); the reference drops it where 256 (b - t) + r >= n_ref,
+// i.e. - n_ref being a multiple of 256 - for whole block distances delta = b - t >= dmin(b), whatever the predelay.  With
+// predelay = 256 a + c the segment index is 256 kappa + r - c, kappa = delta - a - p in {0, 1, 2}: per kappa the dropped terms of
+// block b are ONE slice of IFFT512( sum_{p >= dmin - a - kappa} g(t) H_p X_{b - kappa - a - p} ) - a partition sum over the LAST
+// few partitions only (at most predelay / 256 - 2 of them; ONE at the shipped operating point) and one inverse transform, against
+// up to 255 x 256 multiply-adds per block, voice and path in the time domain.  Same spectra, gains and segments as the
+// partition sums themselves (k_mac_* / k_inv): exact up to fp32 rounding.
+// lds: FFT_WAVE_LDS wave-private complex entries; lane holds frames r = 4 lane .. 4 lane + 3 of block b.
+__device__ __forceinline__ void tail_drop_fft(const TailDrop& td, float2* lds, const float2* s_tw, int64_t b, bool active, int64_t pd,
+                                              int64_t n_ref, int pm, int64_t blo, int lane, float (&dl)[4], float (&dr)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) dl[q] = dr[q] = 0.f;
+    const int64_t v_own = (b << 8) - n_ref;
+    if (!active || v_own < 0) return;  // (wave-uniform; nothing below involves another wave)
+    const int64_t hi = ((v_own >> 8) / pm + 1) * pm - 1;  // last source block whose contribution this block has lost
+    const int64_t dmin = b - hi;
+    const int a = (int)(pd >> 8), c = (int)(pd & 255);
+    float4* ybin = reinterpret_cast<float4*>(lds);  // [256] {Y_L, Y_R} per bin, before the transform reuses the tile
+    for (int kappa = 0; kappa < 3; kappa++) {
+        if (kappa == 2 && c == 0) break;
+        float4 y[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) y[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any = false;
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+            if (vi >= td.nv) break;
+            const int pmax = max(td.P0[vi], td.P1[vi]);
+            int64_t p_lo = dmin - a - kappa;
+            if (p_lo < 0) p_lo = 0;
+            for (int64_t p = p_lo; p < pmax; p++) {
+                const int64_t t = b - kappa - a - p;
+                if (t < blo || t < 0) break;
+                const int slot = (int)(t & (td.ring - 1));
+                const float4 g = td.slotgain[(size_t)vi * td.ring + slot];
+                if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+                any = true;
+                const bool in0 = p < td.P0[vi], in1 = p < td.P1[vi];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int k = lane + 64 * rr;
+                    const float4 x = td.fdl[(size_t)k * td.ring + slot];
+                    const float4 h0 = in0 ? td.H0s[vi][(size_t)k * td.pstride_ir + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 h1 = in1 ? td.H1s[vi][(size_t)k * td.pstride_ir + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                    if (k == 0) {  // bin 0 packs {DC, Nyquist}: two real products
+                        cmac<true>(a0, h0.x, h0.y, x.x, x.y);
+                        cmac<true>(a1, h1.x, h1.y, x.z, x.w);
+                        cmac<true>(a2, h0.z, h0.w, x.x, x.y);
+                        cmac<true>(a3, h1.z, h1.w, x.z, x.w);
+                    } else {
+                        cmac<false>(a0, h0.x, h0.y, x.x, x.y);
+                        cmac<false>(a1, h1.x, h1.y, x.z, x.w);
+                        cmac<false>(a2, h0.z, h0.w, x.x, x.y);
+                        cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+                    }
+                    y[rr].x += g.x * a0.x + g.y * a1.x;
+                    y[rr].y += g.x * a0.y + g.y * a1.y;
+                    y[rr].z += g.z * a2.x + g.w * a3.x;
+                    y[rr].w += g.z * a2.y + g.w * a3.y;
+                }
+            }
+        }
+        if (!any) continue;  // (wave-uniform: the same blocks and gains for every lane)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) ybin[lane + 64 * rr] = y[rr];
+        fft_sync<false>();
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {  // Hermitian extension of the packed spectrum Y_L + j Y_R (as k_inv)
+            const int n = lane + 64 * r;
+            float2 w;
+            if (n == 0) {
+                const float4 yy = ybin[0];
+                w = make_float2(yy.x, yy.z);
+            } else if (n == MC_B) {
+                const float4 yy = ybin[0];
+                w = make_float2(yy.y, yy.w);
+            } else if (n < MC_B) {
+                const float4 yy = ybin[n];
+                w = make_float2(yy.x - yy.w, yy.y + yy.z);
+            } else {
+                const float4 yy = ybin[FFT_N - n];
+                w = make_float2(yy.x + yy.w, -yy.y + yy.z);
+            }
+            v[r] = w;
+        }
+        fft_sync<false>();
+        fft512_wave<+1, false>(v, lds, s_tw, lane);
+        const float sc = 1.0f / FFT_N;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 256 * kappa + 4 * lane + q - c;  // segment index of frame r = 4 lane + q
+            if (i >= 0 && i < FFT_N) {
+                const float2 z = lds[i];
+                dl[q] += z.x * sc;
+                dr[q] += z.y * sc;
+            }
+        }
+        fft_sync<false>();
+    }
+}
+
 // k_post's form of the same sum: a workgroup finishes four consecutive output blocks, one wave per block, four consecutive
 // frames per lane.  The tap index of (output sample r of block b, input sample m of source block tb) is
 // 256 (b - tb) + r - pd - m: it depends on the block DISTANCE delta = b - tb only, so the walk goes diagonal by diagonal -
@@ -1650,8 +1765,9 @@ __device__ __forceinline__ float2 wet_at(const float* __restrict__ seg, int sr, 
     return make_float2(0.f, 0.f);
 }
 
-// TD = false: the variant for calls whose Q8 pass is off (no tail_drop code, half the registers)
-template <bool TD>
+// TD = 0: the variant for calls whose Q8 pass is off (no tail-drop code, half the registers); 1: the cut terms in the time
+// domain (tail_drop_tile4); 2: in the frequency domain (tail_drop_fft) - instantiations of their own, each with its registers
+template <int TD>
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
                                               float* wet, int wr, const double* __restrict__ cring, int rc,
                                               const BlockParams* __restrict__ ptab, int pstride,
@@ -1672,11 +1788,23 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     // One wave per block, four consecutive frames per lane (16-byte loads and stores); grid = ceil(count / 4).
     const int tb = blockIdx.x * 4 + (threadIdx.x >> 6);  // block within the slice
     float tdl[4] = {0.f, 0.f, 0.f, 0.f}, tdr[4] = {0.f, 0.f, 0.f, 0.f};
-    if (TD && td.on) {  // the Q8 terms of the workgroup's four blocks (1024 samples), cooperatively (tail_drop_tile)
-        __shared__ __attribute__((aligned(16))) float s_tdx[4 * 2 * 256];
-        __shared__ __attribute__((aligned(32))) float2 s_tdh[2 * 516];
-        tail_drop_tile4(td, s_tdx, s_tdh, tabs0 + first + (int64_t)blockIdx.x * 4, tb < count, tabs0, T, predelay, n_ref, ptab, pstride, rc, in1, in2,
-                        pm, ret.b0, tdl, tdr);
+    if (TD && td.on) {  // the Q8 terms of the workgroup's four blocks (1024 samples)
+        // one region of LDS for either form: the frequency-domain one (a transform tile per wave + the twiddles), or the
+        // time-domain tiles (four source blocks + one window of taps)
+        __shared__ __attribute__((aligned(32))) float2 s_td[4 * FFT_WAVE_LDS + FFT_N];
+        static_assert(sizeof(float2) * (4 * FFT_WAVE_LDS + FFT_N) >= sizeof(float) * 4 * 2 * 256 + sizeof(float2) * 2 * 516, "tile arrays fit");
+        if (TD == 2) {
+            float2* s_tw = s_td + 4 * FFT_WAVE_LDS;
+            load_twiddles(s_tw, td.g_tw);
+            __syncthreads();
+            tail_drop_fft(td, s_td + (threadIdx.x >> 6) * FFT_WAVE_LDS, s_tw, tabs0 + first + tb, tb < count, predelay, n_ref, pm, ret.b0,
+                          (int)(threadIdx.x & 63), tdl, tdr);
+        } else {
+            float* s_tdx = reinterpret_cast<float*>(s_td);
+            float2* s_tdh = s_td + 4 * 2 * 256 / 2;
+            tail_drop_tile4(td, s_tdx, s_tdh, tabs0 + first + (int64_t)blockIdx.x * 4, tb < count, tabs0, T, predelay, n_ref, ptab, pstride, rc, in1, in2,
+                            pm, ret.b0, tdl, tdr);
+        }
     }
     if (tb < count) {
         const int t = first + tb, m0 = (threadIdx.x & 63) * 4;

@@ -780,6 +780,29 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
     td.xhist = e->d_xhist;
     td.xr = e->xr;
     td.gring = e->d_gring;
+    // the frequency-domain form (k_post): fp32 engines whose delay line still holds the blocks the dropped terms come from - up to
+    // n_ref / 256 + 2 blocks before the oldest block of the batch (the ring is Tmax + that much or more for every engine that is not
+    // created with a batch limit far below its fft size; MCCONV_TD_FFT=0: the time-domain tiles)
+    // Measured (profiles/r3_shipped_defaults.md): equal to the time-domain tiles at the shipped operating point (one diagonal, 0.9 ms per
+    // 125 000 blocks either way: the tiles are bound by multiply-add issue, this form by its chains of dependent loads at two waves per
+    // SIMD), 10 % slower at 13 diagonals with an unaligned predelay, 25 % faster at 29 (predelay 8192): used from 20 diagonals on;
+    // MCCONV_TD_FFT=1 / 0 force it on / off
+    static const int want_fft = std::getenv("MCCONV_TD_FFT") ? std::atoi(std::getenv("MCCONV_TD_FFT")) : -1;
+    const int64_t ndiag = ((int64_t)lmax + (int64_t)predelay + 254) / MC_B - (int64_t)(e->cfg.n_ref / MC_B) + 1;
+    for (int v = 0; v < MC_MAXV; v++) {
+        const IrEntry* a = vir[0][v] >= 0 ? &e->irs[vir[0][v]] : nullptr;
+        const IrEntry* b = vir[1][v] >= 0 ? &e->irs[vir[1][v]] : nullptr;
+        td.H0s[v] = a ? a->d_H : (fb ? fb->d_H : nullptr);
+        td.H1s[v] = b ? b->d_H : (fb ? fb->d_H : nullptr);
+        td.P0[v] = a ? a->P : 0;
+        td.P1[v] = b ? b->P : 0;
+    }
+    td.pstride_ir = e->Pstride;
+    td.fdl = e->d_fdl;
+    td.slotgain = e->d_slotgain;
+    td.ring = e->ring;
+    td.g_tw = e->d_tw;
+    td.fft = ((want_fft > 0 || (want_fft < 0 && ndiag >= 20)) && !e->half && (uint64_t)e->ring >= (uint64_t)e->Tmax + e->cfg.n_ref / MC_B + 40) ? 1 : 0;
     return td;
 }
 
@@ -1583,7 +1606,7 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const int post_first = lin_slice ? lin_first : ctx.first;
         const int post_count = lin_slice ? lin_count : (ctx.out_from >= 0 ? ctx.out_from : ctx.count);
         if (post_count > 0)
-        hipLaunchKernelGGL(td.on ? k_post<true> : k_post<false>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
+        hipLaunchKernelGGL(td.on ? (td.fft ? k_post<2> : k_post<1>) : k_post<0>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, post_first, post_count,
                            ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
