@@ -1288,7 +1288,7 @@ struct TailDrop {
     float* xhist;   // [2][xr] input history ring (absolute sample index mod xr)
     int xr;
     float4* gring;  // [MC_MAXV][rc] wet gains of past blocks
-    // frequency-domain form of the same terms (tail_drop_fft, k_post): the voices' partition spectra, the delay line and
+    // frequency-domain form of the same terms (k_drop_fft): the voices' partition spectra, the delay line and
     // its slot gains (both indexed by absolute block mod ring), the transform's twiddles; fft != 0: use it
     int fft;
     const float4* H0s[MC_MAXV];  // [256 bins][pstride_ir] {H_L, H_R} of voice v's IR for input 1
@@ -1299,6 +1299,10 @@ struct TailDrop {
     const float4* slotgain;
     int ring;
     const float2* g_tw;
+    const float4* Ht0[MC_MAXV];  // the same spectra partition-major for the last partitions, [P - tp][256] (null: read the bank)
+    const float4* Ht1[MC_MAXV];
+    int tp0[MC_MAXV], tp1[MC_MAXV];
+    const float2* dropbuf;  // fft == 2: the terms of the launch's blocks, [count][256] {L, R}, summed by k_drop_fft ahead of k_post
 };
 
 __device__ __forceinline__ void tail_drop(const TailDrop& td, int64_t tau, int64_t tau0, int T, int64_t pd, int64_t n_ref,
@@ -1502,62 +1506,122 @@ __device__ __forceinline__ void tail_drop_tile(const TailDrop& td, float* s_x, f
     __syncthreads();  // (the caller may reuse the arrays)
 }
 
-// The same terms in the frequency domain (k_post, one wave per output block; round 3).  Block t's contribution at lag s from
+// The same terms in the frequency domain (round 3).  Block t's contribution at lag s from
 // its start is sum_p seg_{t,p}[s - 256 p], seg_{t,p} = IFFT512(X_t H_p); the reference drops it where 256 (b - t) + r >= n_ref,
 // i.e. - n_ref being a multiple of 256 - for whole block distances delta = b - t >= dmin(b), whatever the predelay.  With
 // predelay = 256 a + c the segment index is 256 kappa + r - c, kappa = delta - a - p in {0, 1, 2}: per kappa the dropped terms of
 // block b are ONE slice of IFFT512( sum_{p >= dmin - a - kappa} g(t) H_p X_{b - kappa - a - p} ) - a partition sum over the LAST
-// few partitions only (at most predelay / 256 - 2 of them; ONE at the shipped operating point) and one inverse transform, against
+// few partitions only (at most predelay / 256 + 2 of them; ONE at the shipped operating point) and one inverse transform, against
 // up to 255 x 256 multiply-adds per block, voice and path in the time domain.  Same spectra, gains and segments as the
 // partition sums themselves (k_mac_* / k_inv): exact up to fp32 rounding.
-// lds: FFT_WAVE_LDS wave-private complex entries; lane holds frames r = 4 lane .. 4 lane + 3 of block b.
-__device__ __forceinline__ void tail_drop_fft(const TailDrop& td, float2* lds, const float2* s_tw, int64_t b, bool active, int64_t pd,
-                                              int64_t n_ref, int pm, int64_t blo, int lane, float (&dl)[4], float (&dr)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) dl[q] = dr[q] = 0.f;
-    const int64_t v_own = (b << 8) - n_ref;
-    if (!active || v_own < 0) return;  // (wave-uniform; nothing below involves another wave)
-    const int64_t hi = ((v_own >> 8) / pm + 1) * pm - 1;  // last source block whose contribution this block has lost
-    const int64_t dmin = b - hi;
+
+// partition-major copy of partitions [p0, P) of an IR's spectra (H: [256 bins][pstride]) -> Ht[(p - p0) * 256 + bin]; grid = span
+__global__ void k_h_tail(const float4* __restrict__ H, int pstride, int p0, int P, float4* __restrict__ Ht) {
+    const int p = p0 + (int)blockIdx.x, k = threadIdx.x;
+    Ht[(size_t)blockIdx.x * MC_NB + k] = p < P ? H[(size_t)k * pstride + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// A launch of its own ahead of k_post (k_post<3> only loads the result).  The first version sat inside k_post, one wave per block: 64
+// lanes read 64 different 128-byte lines of the delay line per load, behind a chain of dependent round trips (gains, then spectra) at
+// two waves per SIMD - 0.9 ms per 125 000 blocks, the same as the time-domain tiles.  Here a workgroup takes DF_WAVES = 8 consecutive
+// output blocks: thread (k0 = tid / 8, col = tid % 8) sums bins k0 + 64 r of block col - the delay line is bin-major, so the 8 columns
+// of one bin are one 128-byte line - into a [256 bins][DF_WAVES + 1] tile in LDS, wave w then transforms column w and keeps the slice
+// of block w's frames; per kappa one partition sum over the last partitions and one inverse transform, as above.  0.40 ms per
+// 125 000 blocks at the shipped operating point (one term): without the sum 0.27, without the transform 0.29 (-DDF_DBG=1 / 2); what is
+// left is latency per workgroup at 16 waves per CU (k_inv_wet runs the same transforms at 32).  drop: [count][256] {L, R}.
+#ifndef DF_WAVES
+#define DF_WAVES 8
+#endif
+#ifndef DF_EU
+#define DF_EU 4  // 128 registers: two workgroups per CU (the kernel wants 138; at 80 it spills 51 and takes twice as long)
+#endif
+__global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(DF_EU, DF_EU))) void k_drop_fft(TailDrop td, float2* __restrict__ drop, int64_t tabs0, int first,
+                                                                                                        int count, int64_t pd, int64_t n_ref, int pm, int64_t blo) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ __align__(16) float2 s_mem[DF_WAVES * FFT_WAVE_LDS];
+    static_assert(sizeof(float2) * DF_WAVES * FFT_WAVE_LDS >= sizeof(float4) * MC_NB * (DF_WAVES + 1), "tile fits the transform buffers");
+    float4(*s_tile)[DF_WAVES + 1] = reinterpret_cast<float4(*)[DF_WAVES + 1]>(s_mem);
+    load_twiddles(s_tw, td.g_tw);
+    // workgroup ids 8 apart run on one XCD: each XCD takes a contiguous run of tiles (as k_inv_wet)
+    int tile;
+    {
+        const int nt = (int)gridDim.x, q = nt >> 3, r = nt & 7, xc = (int)blockIdx.x & 7;
+        tile = xc * q + min(xc, r) + ((int)blockIdx.x >> 3);
+#ifdef DF_LINEAR
+        tile = (int)blockIdx.x;
+#endif
+    }
+    const int tb0 = tile * DF_WAVES;
+    const int col = threadIdx.x % DF_WAVES, k0 = threadIdx.x / DF_WAVES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a = (int)(pd >> 8), c = (int)(pd & 255);
-    float4* ybin = reinterpret_cast<float4*>(lds);  // [256] {Y_L, Y_R} per bin, before the transform reuses the tile
+    // the summing role: block b_s = column col; the transforming role: block b_w = column wave
+    const int64_t b_s = tabs0 + first + tb0 + col, b_w = tabs0 + first + tb0 + wave;
+    const bool act_s = tb0 + col < count && (b_s << 8) >= n_ref, act_w = tb0 + wave < count && (b_w << 8) >= n_ref;
+    int dmin_s = 0;
+    if (act_s) {
+        const int64_t v_own = (b_s << 8) - n_ref;
+        dmin_s = (int)(b_s - (((v_own >> 8) / pm + 1) * pm - 1));  // block distances >= dmin_s are cut
+    }
+    float dl[4] = {0.f, 0.f, 0.f, 0.f}, dr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
     for (int kappa = 0; kappa < 3; kappa++) {
         if (kappa == 2 && c == 0) break;
+        const int p_lo = max(dmin_s - a - kappa, 0);
+        bool any = false;  // (from the partition counts alone: a voice whose gains are all zero adds zeros)
+        if (act_s)
+            for (int vi = 0; vi < td.nv; vi++) any = any || p_lo < max(td.P0[vi], td.P1[vi]);
+        if (!__syncthreads_or(any ? 1 : 0)) continue;  // no block of the tile has a term at this kappa (also: the buffers are free again)
+        // per partition ONE round trip: the column's gains, the four rows of bins (k0 + 64 rr) and their spectra are requested together, with
+        // no branch between them.  The partition index runs over the tile's common range as a scalar (uniform bases and strides); a column
+        // whose own range starts later (periods of 2 or 4 blocks), or whose source block lies before the epoch, gets zero gains; so does the
+        // input whose IR has no such partition (the bank is zero beyond an IR's last partition, but a voice without an IR points at another one's)
         float4 y[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) y[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool any = false;
-#pragma unroll
-        for (int vi = 0; vi < MC_MAXV; vi++) {
-            if (vi >= td.nv) break;
-            const int pmax = max(td.P0[vi], td.P1[vi]);
-            int64_t p_lo = dmin - a - kappa;
-            if (p_lo < 0) p_lo = 0;
-            for (int64_t p = p_lo; p < pmax; p++) {
-                const int64_t t = b - kappa - a - p;
-                if (t < blo || t < 0) break;
-                const int slot = (int)(t & (td.ring - 1));
-                const float4 g = td.slotgain[(size_t)vi * td.ring + slot];
-                if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
-                any = true;
-                const bool in0 = p < td.P0[vi], in1 = p < td.P1[vi];
+        const int p_lo_u = max((int)(n_ref >> 8) - pm + 1 - a - kappa, 0);
+#pragma unroll 1
+        for (int vi = 0; vi < td.nv; vi++) {
+            const int P0 = td.P0[vi], P1 = td.P1[vi], pmax = max(P0, P1);
+            const float4* __restrict__ sg = td.slotgain + (size_t)vi * td.ring;
+#pragma unroll 1
+#if defined(DF_DBG) && DF_DBG == 1  // (timing ablation: no partition sum)
+            for (int p = p_lo_u; p < pmax && pd < 0; p++) {
+#else
+            for (int p = p_lo_u; p < pmax; p++) {
+#endif
+                const int64_t t = b_s - kappa - a - p;
+                const bool ok = act_s && p >= p_lo && t >= blo && t >= 0;
+                const unsigned slot = (unsigned)(t < 0 ? 0 : t) & (unsigned)(td.ring - 1);
+                const bool t0 = td.Ht0[vi] && p >= td.tp0[vi], t1 = td.Ht1[vi] && p >= td.tp1[vi];  // (uniform)
+                const float4* __restrict__ B0 = t0 ? td.Ht0[vi] + (size_t)(p - td.tp0[vi]) * MC_NB : td.H0s[vi] + p;
+                const float4* __restrict__ B1 = t1 ? td.Ht1[vi] + (size_t)(p - td.tp1[vi]) * MC_NB : td.H1s[vi] + p;
+                const unsigned s0 = t0 ? 1u : (unsigned)td.pstride_ir, s1 = t1 ? 1u : (unsigned)td.pstride_ir;
+                const unsigned xo = (unsigned)k0 * (unsigned)td.ring + slot, xs = 64u * (unsigned)td.ring;
+                float4 g = sg[slot];
+                float4 x[4], h0[4], h1[4];
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
-                    const int k = lane + 64 * rr;
-                    const float4 x = td.fdl[(size_t)k * td.ring + slot];
-                    const float4 h0 = in0 ? td.H0s[vi][(size_t)k * td.pstride_ir + p] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 h1 = in1 ? td.H1s[vi][(size_t)k * td.pstride_ir + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const unsigned k = (unsigned)k0 + 64u * rr;
+                    x[rr] = td.fdl[xo + rr * xs];
+                    h0[rr] = B0[k * s0];
+                    h1[rr] = B1[k * s1];
+                }
+                const bool m0 = ok && p < P0, m1 = ok && p < P1;
+                g.x = m0 ? g.x : 0.f, g.z = m0 ? g.z : 0.f;
+                g.y = m1 ? g.y : 0.f, g.w = m1 ? g.w : 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
                     float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-                    if (k == 0) {  // bin 0 packs {DC, Nyquist}: two real products
-                        cmac<true>(a0, h0.x, h0.y, x.x, x.y);
-                        cmac<true>(a1, h1.x, h1.y, x.z, x.w);
-                        cmac<true>(a2, h0.z, h0.w, x.x, x.y);
-                        cmac<true>(a3, h1.z, h1.w, x.z, x.w);
-                    } else {
-                        cmac<false>(a0, h0.x, h0.y, x.x, x.y);
-                        cmac<false>(a1, h1.x, h1.y, x.z, x.w);
-                        cmac<false>(a2, h0.z, h0.w, x.x, x.y);
-                        cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+                    cmac<false>(a0, h0[rr].x, h0[rr].y, x[rr].x, x[rr].y);
+                    cmac<false>(a1, h1[rr].x, h1[rr].y, x[rr].z, x[rr].w);
+                    cmac<false>(a2, h0[rr].z, h0[rr].w, x[rr].x, x[rr].y);
+                    cmac<false>(a3, h1[rr].z, h1[rr].w, x[rr].z, x[rr].w);
+                    if (rr == 0 && k0 == 0) {  // bin 0 packs {DC, Nyquist}: two real products
+                        a0 = make_float2(h0[0].x * x[0].x, h0[0].y * x[0].y);
+                        a1 = make_float2(h1[0].x * x[0].z, h1[0].y * x[0].w);
+                        a2 = make_float2(h0[0].z * x[0].x, h0[0].w * x[0].y);
+                        a3 = make_float2(h1[0].z * x[0].z, h1[0].w * x[0].w);
                     }
                     y[rr].x += g.x * a0.x + g.y * a1.x;
                     y[rr].y += g.x * a0.y + g.y * a1.y;
@@ -1566,43 +1630,55 @@ __device__ __forceinline__ void tail_drop_fft(const TailDrop& td, float2* lds, c
                 }
             }
         }
-        if (!any) continue;  // (wave-uniform: the same blocks and gains for every lane)
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) ybin[lane + 64 * rr] = y[rr];
-        fft_sync<false>();
+        for (int rr = 0; rr < 4; rr++) s_tile[k0 + 64 * rr][col] = y[rr];
+        __syncthreads();
         float2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {  // Hermitian extension of the packed spectrum Y_L + j Y_R (as k_inv)
             const int n = lane + 64 * r;
             float2 w;
             if (n == 0) {
-                const float4 yy = ybin[0];
+                const float4 yy = s_tile[0][wave];
                 w = make_float2(yy.x, yy.z);
             } else if (n == MC_B) {
-                const float4 yy = ybin[0];
+                const float4 yy = s_tile[0][wave];
                 w = make_float2(yy.y, yy.w);
             } else if (n < MC_B) {
-                const float4 yy = ybin[n];
+                const float4 yy = s_tile[n][wave];
                 w = make_float2(yy.x - yy.w, yy.y + yy.z);
             } else {
-                const float4 yy = ybin[FFT_N - n];
+                const float4 yy = s_tile[FFT_N - n][wave];
                 w = make_float2(yy.x + yy.w, -yy.y + yy.z);
             }
             v[r] = w;
         }
-        fft_sync<false>();
-        fft512_wave<+1, false>(v, lds, s_tw, lane);
-        const float sc = 1.0f / FFT_N;
+        __syncthreads();  // the tile is in registers: its memory becomes the transform buffers
+        if (act_w) {
+            float2* lds = s_mem + wave * FFT_WAVE_LDS;
+#if defined(DF_DBG) && DF_DBG == 2  // (timing ablation: no transform)
+            lds[lane] = v[0], lds[lane + 64] = v[1], lds[lane + 128] = v[2], lds[lane + 192] = v[3];
+            lds[lane + 256] = v[4], lds[lane + 320] = v[5], lds[lane + 384] = v[6], lds[lane + 448] = v[7];
+#else
+            fft512_wave<+1, false>(v, lds, s_tw, lane);
+#endif
+            const float sc = 1.0f / FFT_N;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = 256 * kappa + 4 * lane + q - c;  // segment index of frame r = 4 lane + q
-            if (i >= 0 && i < FFT_N) {
-                const float2 z = lds[i];
-                dl[q] += z.x * sc;
-                dr[q] += z.y * sc;
+            for (int q = 0; q < 4; q++) {
+                const int i = 256 * kappa + 4 * lane + q - c;  // segment index of frame r = 4 lane + q
+                if (i >= 0 && i < FFT_N) {
+                    const float2 z = lds[i];
+                    dl[q] += z.x * sc;
+                    dr[q] += z.y * sc;
+                }
             }
         }
-        fft_sync<false>();
+        __syncthreads();
+    }
+    if (tb0 + wave < count) {
+        float4* dst = reinterpret_cast<float4*>(drop + (size_t)(tb0 + wave) * MC_B + 4 * lane);
+        dst[0] = make_float4(dl[0], dr[0], dl[1], dr[1]);
+        dst[1] = make_float4(dl[2], dr[2], dl[3], dr[3]);
     }
 }
 
@@ -1766,7 +1842,8 @@ __device__ __forceinline__ float2 wet_at(const float* __restrict__ seg, int sr, 
 }
 
 // TD = 0: the variant for calls whose Q8 pass is off (no tail-drop code, half the registers); 1: the cut terms in the time
-// domain (tail_drop_tile4); 2: in the frequency domain (tail_drop_fft) - instantiations of their own, each with its registers
+// domain (tail_drop_tile4); 3: loaded - summed in the frequency domain by k_drop_fft ahead of the launch (2 was that sum inside this
+// kernel, one wave per block: no faster than the tiles, see k_drop_fft) - instantiations of their own, each with its registers
 template <int TD>
 __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int sr, const float* __restrict__ lin,
                                               float* wet, int wr, const double* __restrict__ cring, int rc,
@@ -1788,23 +1865,18 @@ __global__ __launch_bounds__(256) void k_post(const float* __restrict__ seg, int
     // One wave per block, four consecutive frames per lane (16-byte loads and stores); grid = ceil(count / 4).
     const int tb = blockIdx.x * 4 + (threadIdx.x >> 6);  // block within the slice
     float tdl[4] = {0.f, 0.f, 0.f, 0.f}, tdr[4] = {0.f, 0.f, 0.f, 0.f};
-    if (TD && td.on) {  // the Q8 terms of the workgroup's four blocks (1024 samples)
-        // one region of LDS for either form: the frequency-domain one (a transform tile per wave + the twiddles), or the
-        // time-domain tiles (four source blocks + one window of taps)
-        __shared__ __attribute__((aligned(32))) float2 s_td[4 * FFT_WAVE_LDS + FFT_N];
-        static_assert(sizeof(float2) * (4 * FFT_WAVE_LDS + FFT_N) >= sizeof(float) * 4 * 2 * 256 + sizeof(float2) * 2 * 516, "tile arrays fit");
-        if (TD == 2) {
-            float2* s_tw = s_td + 4 * FFT_WAVE_LDS;
-            load_twiddles(s_tw, td.g_tw);
-            __syncthreads();
-            tail_drop_fft(td, s_td + (threadIdx.x >> 6) * FFT_WAVE_LDS, s_tw, tabs0 + first + tb, tb < count, predelay, n_ref, pm, ret.b0,
-                          (int)(threadIdx.x & 63), tdl, tdr);
-        } else {
-            float* s_tdx = reinterpret_cast<float*>(s_td);
-            float2* s_tdh = s_td + 4 * 2 * 256 / 2;
-            tail_drop_tile4(td, s_tdx, s_tdh, tabs0 + first + (int64_t)blockIdx.x * 4, tb < count, tabs0, T, predelay, n_ref, ptab, pstride, rc, in1, in2,
-                            pm, ret.b0, tdl, tdr);
+    if (TD == 3) {  // summed by k_drop_fft ahead of this launch
+        if (tb < count) {
+            const float4* src = reinterpret_cast<const float4*>(td.dropbuf + (size_t)tb * MC_B + 4 * (threadIdx.x & 63));
+            const float4 u = src[0], w = src[1];
+            tdl[0] = u.x, tdr[0] = u.y, tdl[1] = u.z, tdr[1] = u.w;
+            tdl[2] = w.x, tdr[2] = w.y, tdl[3] = w.z, tdr[3] = w.w;
         }
+    } else if (TD && td.on) {  // the Q8 terms of the workgroup's four blocks (1024 samples): four source blocks + one window of taps in LDS
+        __shared__ __attribute__((aligned(32))) float s_tdx[4 * 2 * 256];
+        __shared__ __attribute__((aligned(32))) float2 s_tdh[2 * 516];
+        tail_drop_tile4(td, s_tdx, s_tdh, tabs0 + first + (int64_t)blockIdx.x * 4, tb < count, tabs0, T, predelay, n_ref, ptab, pstride, rc, in1, in2,
+                        pm, ret.b0, tdl, tdr);
     }
     if (tb < count) {
         const int t = first + tb, m0 = (threadIdx.x & 63) * 4;

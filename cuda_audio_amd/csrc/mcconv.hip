@@ -69,6 +69,9 @@ struct IrEntry {
     float2* d_G2 = nullptr;  // second-level spectra for the fused 8192-point form [2 ch][257 rows][G2_N]
     bool g2_valid = false;
     float2* d_h = nullptr;  // time-domain taps {L, R} (Q8 pass)
+    float4* d_Htail = nullptr;  // Q8 pass, frequency-domain form: the last partitions' spectra partition-major [P - tail_p0][256] (ensure_htail)
+    int tail_p0 = 0;
+    bool tail_valid = false;
     float2* d_S = nullptr;   // single-transform form (mc_config.form = 1): [H_L | H_R], n_ref / 2 bins each
     uint2* d_H16 = nullptr;  // fp16 copy of the spectra, scaled by scale16 (precision = fp16)
     float scale16 = 1.f;
@@ -245,6 +248,8 @@ struct mc_engine {
     int spec_nact = 0;
     hipEvent_t ev_tail = nullptr;
     float4* d_part_jack[2] = {nullptr, nullptr};  // JACK path: the sweep's partials, double-buffered by block parity
+    bool td_fft = true;                           // Q8 regime, batches: the cut terms in the frequency domain (MCCONV_TD_FFT=0: time-domain tiles)
+    float2* d_dropbuf = nullptr;                  // batches, Q8 regime: the cut terms of a batch's blocks [Tmax][256] {L, R} (k_drop_fft), allocated by the first such batch
     float* d_drop[2] = {nullptr, nullptr};        // JACK path, Q8 regime: a period's tail-drop terms [2][1024] (k_drop_period), by period parity
     JackPre pre;                     // the period parked one call ahead
     bool park = true;                // MCCONV_NO_PARK=1: every period launched when it arrives
@@ -453,8 +458,25 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force);
 // components - is rebuilt on next use.  (Round 2 built the fast-FIR components eagerly at every load: 60 MB and three
 // launches per 10 s IR for a form that only MCCONV_FFT2=0 selects.)
 void invalidate_derived(IrEntry& ir) {
-    ir.h2_valid = ir.g2_valid = false;
+    ir.h2_valid = ir.g2_valid = ir.tail_valid = false;
     ir.hp_valid[0] = ir.hp_valid[1] = ir.hp_valid[2] = false;
+}
+// The last partitions of an IR's spectra, partition-major, for k_drop_fft: every workgroup of that launch reads the same few
+// partitions of all 256 bins, and in the bin-major bank those entries lie Pstride * 16 bytes apart (one 128-byte line fetched per
+// 16 bytes used, all of them in one L2 channel).  Worth 2-4 % of the step (scripts/gpu_q8_pd.sh, MCCONV_HTAIL=0 turns it off): the launch
+// is bound by its latency per workgroup, not by these reads.  kTailSpan partitions cover every predelay the controllers can reach
+// (8192 frames = 32 partitions, + 2); a term outside falls back to the bank.
+constexpr int kTailSpan = 48;
+int ensure_htail(mc_engine* e, const IrEntry* irc) {
+    IrEntry& ir = *const_cast<IrEntry*>(irc);
+    static const bool off = std::getenv("MCCONV_HTAIL") && std::atoi(std::getenv("MCCONV_HTAIL")) == 0;
+    if (ir.tail_valid || !ir.d_H || off) return MC_OK;
+    if (!ir.d_Htail) HIP_TRY(hipMalloc(&ir.d_Htail, sizeof(float4) * (size_t)kTailSpan * MC_NB));
+    ir.tail_p0 = std::max(0, ir.P - kTailSpan);
+    hipLaunchKernelGGL(k_h_tail, dim3(kTailSpan), dim3(MC_NB), 0, e->stream, (const float4*)ir.d_H, e->Pstride, ir.tail_p0, ir.P, ir.d_Htail);
+    HIP_TRY(hipGetLastError());
+    ir.tail_valid = true;
+    return MC_OK;
 }
 // whether the fast-FIR form of level lvl (1..3) exists for this engine at all
 bool hp_possible(const mc_engine* e, int lvl) {
@@ -780,15 +802,10 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
     td.xhist = e->d_xhist;
     td.xr = e->xr;
     td.gring = e->d_gring;
-    // the frequency-domain form (k_post): fp32 engines whose delay line still holds the blocks the dropped terms come from - up to
-    // n_ref / 256 + 2 blocks before the oldest block of the batch (the ring is Tmax + that much or more for every engine that is not
-    // created with a batch limit far below its fft size; MCCONV_TD_FFT=0: the time-domain tiles)
-    // Measured (profiles/r3_shipped_defaults.md): equal to the time-domain tiles at the shipped operating point (one diagonal, 0.9 ms per
-    // 125 000 blocks either way: the tiles are bound by multiply-add issue, this form by its chains of dependent loads at two waves per
-    // SIMD), 10 % slower at 13 diagonals with an unaligned predelay, 25 % faster at 29 (predelay 8192): used from 20 diagonals on;
-    // MCCONV_TD_FFT=1 / 0 force it on / off
-    static const int want_fft = std::getenv("MCCONV_TD_FFT") ? std::atoi(std::getenv("MCCONV_TD_FFT")) : -1;
-    const int64_t ndiag = ((int64_t)lmax + (int64_t)predelay + 254) / MC_B - (int64_t)(e->cfg.n_ref / MC_B) + 1;
+    // the frequency-domain form (k_drop_fft ahead of k_post<3>): fp32 engines whose delay line still holds the blocks the dropped terms come
+    // from - up to n_ref / 256 + 2 blocks before the oldest block of the batch (the ring is Tmax + that much or more for every engine that is
+    // not created with a batch limit far below its fft size).  MCCONV_TD_FFT=0 (read when the engine is created): the time-domain tiles inside k_post<1> (profiles/r3_shipped_defaults.md
+    // has both: 0.40 + 0.21 ms against 0.90 ms per 125 000 blocks at the shipped operating point, 2.5 against 22 ms per step at predelay 8192)
     for (int v = 0; v < MC_MAXV; v++) {
         const IrEntry* a = vir[0][v] >= 0 ? &e->irs[vir[0][v]] : nullptr;
         const IrEntry* b = vir[1][v] >= 0 ? &e->irs[vir[1][v]] : nullptr;
@@ -796,13 +813,17 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
         td.H1s[v] = b ? b->d_H : (fb ? fb->d_H : nullptr);
         td.P0[v] = a ? a->P : 0;
         td.P1[v] = b ? b->P : 0;
+        td.Ht0[v] = a && a->tail_valid ? a->d_Htail : nullptr;
+        td.Ht1[v] = b && b->tail_valid ? b->d_Htail : nullptr;
+        td.tp0[v] = a && a->tail_valid ? a->tail_p0 : 0;
+        td.tp1[v] = b && b->tail_valid ? b->tail_p0 : 0;
     }
     td.pstride_ir = e->Pstride;
     td.fdl = e->d_fdl;
     td.slotgain = e->d_slotgain;
     td.ring = e->ring;
     td.g_tw = e->d_tw;
-    td.fft = ((want_fft > 0 || (want_fft < 0 && ndiag >= 20)) && !e->half && (uint64_t)e->ring >= (uint64_t)e->Tmax + e->cfg.n_ref / MC_B + 40) ? 1 : 0;
+    td.fft = (e->td_fft && !e->half && (uint64_t)e->ring >= (uint64_t)e->Tmax + e->cfg.n_ref / MC_B + 40) ? 1 : 0;
     return td;
 }
 
@@ -1594,6 +1615,19 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
             if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);  // a single chunk adds its base itself
         }
+        {  // Q8 regime, frequency-domain form: the voices' last partitions partition-major (first batch that needs them)
+            uint64_t lmax = 0;
+            for (int h = 0; h < 2; h++)
+                for (int v = 0; v < MC_MAXV; v++)
+                    if (ctx.vir[h][v] >= 0) lmax = std::max<uint64_t>(lmax, e->irs[ctx.vir[h][v]].taps);
+            if (e->cfg.compat && lmax + 255 + ctx.predelay > e->cfg.n_ref && !e->half)
+                for (int h = 0; h < 2; h++)
+                    for (int v = 0; v < MC_MAXV; v++)
+                        if (ctx.vir[h][v] >= 0) {
+                            const int rc_t = ensure_htail(e, &e->irs[ctx.vir[h][v]]);
+                            if (rc_t != MC_OK) return rc_t;
+                        }
+        }
         const bool piped = e->pipelined && !lin_sum && !publish;
         hipStream_t ps = e->stream;
         if (piped) {  // k_post follows this batch's inverse transforms on the post stream, after the prefix sums
@@ -1601,12 +1635,19 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             HIP_TRY(hipStreamWaitEvent(e->post_stream, e->ev_corr[ctx.slot], 0));
             ps = e->post_stream;
         }
-        const TailDrop td = make_taildrop(e, ctx.vir, ctx.predelay);
+        const TailDrop td_ = make_taildrop(e, ctx.vir, ctx.predelay);
         // the front half finished blocks >= out_from itself: only the blocks the predelay fills from the previous batch remain
         const int post_first = lin_slice ? lin_first : ctx.first;
         const int post_count = lin_slice ? lin_count : (ctx.out_from >= 0 ? ctx.out_from : ctx.count);
+        TailDrop td = td_;
+        if (post_count > 0 && td.on && td.fft) {
+            if (!e->d_dropbuf) HIP_TRY(hipMalloc(&e->d_dropbuf, sizeof(float2) * (size_t)e->Tmax * MC_B));  // (first batch in the regime)
+            hipLaunchKernelGGL(k_drop_fft, dim3((post_count + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, ps, td, e->d_dropbuf, (int64_t)ctx.t0, post_first,
+                               post_count, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
+            td.dropbuf = e->d_dropbuf;
+        }
         if (post_count > 0)
-        hipLaunchKernelGGL(td.on ? (td.fft ? k_post<2> : k_post<1>) : k_post<0>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
+        hipLaunchKernelGGL(td.on ? (td.fft ? k_post<3> : k_post<1>) : k_post<0>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
                            e->rc, d_ptab, ctx.pstride, d_in1, d_in2, d_outL, d_outR, T, (int64_t)ctx.t0, post_first, post_count,
                            ctx.wet_ready ? INT64_MAX : (int64_t)ctx.win0, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, (int)e->cfg.compat,
@@ -2544,6 +2585,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         }                                                                                                 \
     } while (0)
 
+    if (const char* v = std::getenv("MCCONV_TD_FFT")) e->td_fft = std::atoi(v) != 0;
     ENG_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     {
@@ -2743,6 +2785,8 @@ void mc_destroy(mc_engine* e) {
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_G2) (void)hipFree(e->irs[i].d_G2);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
+        if (e->irs[i].d_Htail) (void)hipFree(e->irs[i].d_Htail);
+    for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_h) (void)hipFree(e->irs[i].d_h);
     for (int i = 0; i < kMaxIrs + kMixIrs; i++)
         if (e->irs[i].d_H16) (void)hipFree(e->irs[i].d_H16);
@@ -2801,6 +2845,7 @@ void mc_destroy(mc_engine* e) {
     if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
     (void)hipFree(e->d_part_jack[0]);
     (void)hipFree(e->d_part_jack[1]);
+    (void)hipFree(e->d_dropbuf);
     (void)hipFree(e->d_drop[0]);
     (void)hipFree(e->d_drop[1]);
     if (e->kev_created)
@@ -2864,6 +2909,10 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
         return fail(MC_ERR_HIP, "IR preparation failed: %s", hipGetErrorString(er));
     }
     if (ir.d_h) (void)hipFree(ir.d_h);
+    if (ir.d_Htail) {
+        (void)hipFree(ir.d_Htail);
+        ir.d_Htail = nullptr;
+    }
     ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
     invalidate_derived(ir);
     for (int l = 0; l < 3; l++)  // (a reloaded IR gives its fast-FIR components back; the stream is idle here)

@@ -452,12 +452,18 @@ def test_config4_eight_channels_sharded(oracle_mod, gpu_lib):
 
 @pytest.mark.parametrize("n_ref,taps,pd", [(4096, (2500, 3072), 1024), (4096, (3072, 3072), 2000), (16384, (15360, 9000), 8128)],
                          ids=["default_predelay", "pd2000", "max_predelay"])
-@pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
-def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack):
+@pytest.mark.parametrize("jack", [False, True, "tiles"], ids=["batch", "jack", "batch_time_domain"])
+def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack, monkeypatch):
     """Q8: with taps + 255 + predelay > N_ref the reference discards what the predelay shifts past N_ref
     (conv.cu:94-98).  The shipped defaults are in that regime (predelay 1024, IRs truncated to N-1024).
-    Slowly decaying IRs so that the discarded tail is far above the tolerance."""
+    Slowly decaying IRs so that the discarded tail is far above the tolerance.  Batches recompute the cut terms in the
+    frequency domain (k_drop_fft; partition sums over the last partitions), single periods and MCCONV_TD_FFT=0 in the
+    time domain (tiles): all three against the same oracle."""
     from cuda_audio_amd.synth import make_input
+
+    if jack == "tiles":
+        monkeypatch.setenv("MCCONV_TD_FFT", "0")  # (read when the engine is created)
+        jack = False
 
     nb = 3 * n_ref // 256 // 2 + 40
     x = make_input(nb * 256)
@@ -524,6 +530,51 @@ def test_q8_history_across_long_batches(oracle_mod, gpu_lib, sizes):
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
     c.close()
+
+
+@pytest.mark.parametrize("period,form", [(256, "fft"), (512, "fft"), (1024, "fft"), (512, "tiles")])
+def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period, form, monkeypatch):
+    """The Q8 regime with everything that shapes its cut terms at once: two IRs of different length cross-fading on one half
+    (two voices with their own gains per block), an unaligned predelay (three slices of the last partitions' segments
+    contribute), and reference calls of 2 and 4 blocks (the cut is measured from the start of the CALL: block distances
+    differ inside a call).  Batches of whole calls, both forms of the cut terms, against oracle.RefCompat run call by call."""
+    from cuda_audio_amd.synth import make_input
+
+    if form == "tiles":
+        monkeypatch.setenv("MCCONV_TD_FFT", "0")
+    n_ref, pd, pm = 4096, 1100, period // 256
+    ncalls = (3 * n_ref // 256 // 2 + 44) // pm
+    x = make_input(ncalls * period, seed=91)
+    rng = np.random.default_rng(17)
+    irs = []
+    for L in (3072, 2800, 3000):
+        h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (2.0 * L))[:, None]
+        irs.append((h * np.sqrt(0.004 / L)).astype(np.float32))
+    p0, p1 = dict(BASE, predelay=pd, speed=9), dict(BASE, select=1, level=0.9, speed=14)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=6 * pm, period=period)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    switches = {ncalls // 2 - 3: (0, 2), ncalls // 2 + 4: (1, 0), ncalls - 20 // pm: (0, 1)}  # call index -> (half, IR)
+    got = np.zeros((2, ncalls * period), np.float32)
+    want = np.zeros((2, ncalls * period))
+    k = 0
+    while k < ncalls:
+        if k in switches:
+            half, ir = switches[k]
+            ref.set(half, select=ir, vsteps=(p0, p1)[half]["speed"])
+            c.cc[half].value.update(select=ir, vsteps=(p0, p1)[half]["speed"])
+        n = min(5, ncalls - k, min([q for q in switches if q > k] + [ncalls]) - k)
+        s = slice(k * period, (k + n) * period)
+        want[:, s] = ref.process(x[0, s], x[1, s], block=period)
+        got[:, s] = c.process(x[0, s], x[1, s])
+        k += n
+    c.close()
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
 
 
 @pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
@@ -876,9 +927,12 @@ def test_predelay_change_keeps_old_blocks_at_their_offset(oracle_mod, gpu_lib, m
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
 
 
-@pytest.mark.parametrize("mode", ["jack", "batch"])
-def test_predelay_change_in_the_tail_drop_regime(oracle_mod, gpu_lib, mode):
+@pytest.mark.parametrize("mode", ["jack", "batch", "batch_time_domain"])
+def test_predelay_change_in_the_tail_drop_regime(oracle_mod, gpu_lib, mode, monkeypatch):
     """Predelay changes with taps + 255 + predelay > N_ref (Q8 active before and after; the shipped defaults)."""
+    if mode == "batch_time_domain":
+        monkeypatch.setenv("MCCONV_TD_FFT", "0")
+        mode = "batch"
     nb, n_ref = 100, 4096
     events = {0: 1024, 30: 2000, 55: 1024, 75: 0}
     _, _, _, got, want = _run_with_predelay_events(oracle_mod, n_ref, nb, (3072, 3072), events, mode)
