@@ -793,6 +793,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_inv(const float4* __restrict__ Y
 struct OutArgs {
     const float *in1, *in2;  // the batch's input [T * 256] each
     float *outL, *outR;      // the batch's output
+    const float2* drop;      // != null (Q8 regime): the cut terms {L, R} of the batch's output frames, [T * 256] (k_drop_fft), subtracted before the clamp
     float* lin;              // != null (a partition shard): the delayed wet partial [2][out_end * 256] is emitted instead - the
                              // summand of the cross-GPU reduce, what k_ola produces; no window sums, clamp or dry mix
     const BlockParams* ptab;
@@ -966,11 +967,16 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 // four frames of one block, and (predelay, n_ref multiples of four) of one window
                 out_window(oa, u0, win);
                 const BlockParams& bp = oa.ptab[(o0 >> 8) * oa.pstride];
+                float4 d01 = make_float4(0.f, 0.f, 0.f, 0.f), d23 = d01;  // the Q8 cut terms of the four frames {L, R} (as k_post: wet - cut, then the window sums in double)
+                if (oa.drop) {
+                    const float4* dp = reinterpret_cast<const float4*>(oa.drop + o0);
+                    d01 = dp[0], d23 = dp[1];
+                }
                 float4 fl, fr;
-                out_frame(false, wl4.x, wr4.x, x1q.x, x2q.x, bp, win, fl.x, fr.x);
-                out_frame(true, wl4.y, wr4.y, x1q.y, x2q.y, bp, win, fl.y, fr.y);
-                out_frame(false, wl4.z, wr4.z, x1q.z, x2q.z, bp, win, fl.z, fr.z);
-                out_frame(true, wl4.w, wr4.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
+                out_frame(false, wl4.x - d01.x, wr4.x - d01.y, x1q.x, x2q.x, bp, win, fl.x, fr.x);
+                out_frame(true, wl4.y - d01.z, wr4.y - d01.w, x1q.y, x2q.y, bp, win, fl.y, fr.y);
+                out_frame(false, wl4.z - d23.x, wr4.z - d23.y, x1q.z, x2q.z, bp, win, fl.z, fr.z);
+                out_frame(true, wl4.w - d23.z, wr4.w - d23.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
                 const int64_t os = o0 - (int64_t)oa.out_blk0 * MC_B;
                 *reinterpret_cast<float4*>(oa.outL + os) = fl;
                 *reinterpret_cast<float4*>(oa.outR + os) = fr;
@@ -984,7 +990,8 @@ __global__ __launch_bounds__(IW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                     const float b = k == 0 ? wr4.x : (k == 1 ? wr4.y : (k == 2 ? wr4.z : wr4.w));
                     float fl, fr;
                     out_window(oa, u0 + k, win);
-                    out_frame((k & 1) != 0, a, b, oa.in1[o], oa.in2[o], bp, win, fl, fr);
+                    const float2 d = oa.drop ? oa.drop[o] : make_float2(0.f, 0.f);
+                    out_frame((k & 1) != 0, a - d.x, b - d.y, oa.in1[o], oa.in2[o], bp, win, fl, fr);
                     oa.outL[o - (int64_t)oa.out_blk0 * MC_B] = fl;
                     oa.outR[o - (int64_t)oa.out_blk0 * MC_B] = fr;
                 }

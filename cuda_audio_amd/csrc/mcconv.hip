@@ -96,6 +96,7 @@ struct BatchCtx {
     uint64_t win0 = 0;         // first absolute sample whose segments the front half computed
     bool wet_ready = false;    // the front half overlap-added the window into the wet ring (k_inv_wet)
     bool corr_done = false;    // the Q1/Q2 prefix sums of the batch are final (they rode along with the front half's launches)
+    bool drop_done = false;    // Q8 regime: the front half summed the cut terms of the whole batch into d_dropbuf (k_drop_fft)
     int out_from = -1;         // >= 0: the front half finished the output of blocks >= out_from itself (k_inv_wet<true>)
 };
 
@@ -288,6 +289,7 @@ struct mc_engine {
     int g2_pmin = 16;        // shortest block-axis convolution (partitions, uniform gains) of an unsharded engine that takes the
                              // second-level transform (MCCONV_G2_PMIN; round 1: 256)
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
+    bool fuse_drop = true;   // MCCONV_FUSE_DROP=0: Q8 regime: the output through k_post<3> even where the inverse transforms could finish it (measurement)
     bool fuse_out = true;    // MCCONV_FUSE_OUT=0: the output always through k_post (measurement)
     unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
     unsigned* d_cflag = nullptr;    // [ceil(Tmax/256)] launch sequence number per published chunk total
@@ -825,6 +827,24 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
     td.g_tw = e->d_tw;
     td.fft = (e->td_fft && !e->half && (uint64_t)e->ring >= (uint64_t)e->Tmax + e->cfg.n_ref / MC_B + 40) ? 1 : 0;
     return td;
+}
+
+// Q8 regime, frequency-domain form (batches): the voices' last partitions partition-major and the buffer of the cut terms, both made by
+// the first batch that needs them (on the engine's stream, ahead of k_drop_fft)
+int prepare_drop_fft(mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_t predelay) {
+    uint64_t lmax = 0;
+    for (int h = 0; h < 2; h++)
+        for (int v = 0; v < MC_MAXV; v++)
+            if (vir[h][v] >= 0) lmax = std::max<uint64_t>(lmax, e->irs[vir[h][v]].taps);
+    if (!(e->cfg.compat && lmax + 255 + predelay > e->cfg.n_ref) || e->half || !e->td_fft) return MC_OK;
+    for (int h = 0; h < 2; h++)
+        for (int v = 0; v < MC_MAXV; v++)
+            if (vir[h][v] >= 0) {
+                const int rc_t = ensure_htail(e, &e->irs[vir[h][v]]);
+                if (rc_t != MC_OK) return rc_t;
+            }
+    if (!e->d_dropbuf) HIP_TRY(hipMalloc(&e->d_dropbuf, sizeof(float2) * (size_t)e->Tmax * MC_B));
+    return MC_OK;
 }
 
 // JACK path in the Q8 regime: the tail-drop terms of the period that starts at block blk (pm blocks), ahead of its tail kernel
@@ -1511,8 +1531,20 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 // before it, from which the slice's first predelay frames come - unless the stream starts inside the reach-back
                 const int halo_full = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
                 const bool covers = slice ? (n == halo + count && off == 0 && halo == halo_full) : (off == 0 && n == T);
+                // ... and in the Q8 regime when the cut terms come as a buffer (k_drop_fft, whole batches): they depend on the delay line and
+                // the gains only, both complete before the partition sums
+                TailDrop tdq = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
+                const bool drop_buf = tdq.on && tdq.fft && !slice && !lin && e->fuse_drop;
                 bool fuse = lin_fused || (h == 1 && d_outL && d_outR && e->fuse_out && to_wet && !piped && covers &&
-                                          e->res_end <= e->t_front * MC_B && !make_taildrop(e, st.ctx.vir, st.ctx.predelay).on);
+                                          e->res_end <= e->t_front * MC_B && (!tdq.on || drop_buf));
+                if (fuse && tdq.on && !lin_fused) {
+                    const int rc_t = prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
+                    if (rc_t != MC_OK) return rc_t;
+                    tdq = make_taildrop(e, st.ctx.vir, st.ctx.predelay);  // (with the partition-major spectra)
+                    hipLaunchKernelGGL(k_drop_fft, dim3((T + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, inv_stream, tdq, e->d_dropbuf, (int64_t)st.ctx.t0, 0, T,
+                                       (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
+                    stored.drop_done = true;
+                }
                 if (fuse) {
                     if (!mo.corr_done && !lin) {  // the prefix sums as launches of their own, ahead of their reader
                         corr_args();
@@ -1527,6 +1559,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                     oa.outL = d_outL;
                     oa.outR = d_outR;
                     oa.lin = lin;
+                    oa.drop = stored.drop_done ? e->d_dropbuf : nullptr;
                     oa.ptab = d_ptab;
                     oa.pstride = pstride;
                     oa.cring = e->d_cring;
@@ -1615,18 +1648,9 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
             hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);
             if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, e->stream, ca);  // a single chunk adds its base itself
         }
-        {  // Q8 regime, frequency-domain form: the voices' last partitions partition-major (first batch that needs them)
-            uint64_t lmax = 0;
-            for (int h = 0; h < 2; h++)
-                for (int v = 0; v < MC_MAXV; v++)
-                    if (ctx.vir[h][v] >= 0) lmax = std::max<uint64_t>(lmax, e->irs[ctx.vir[h][v]].taps);
-            if (e->cfg.compat && lmax + 255 + ctx.predelay > e->cfg.n_ref && !e->half)
-                for (int h = 0; h < 2; h++)
-                    for (int v = 0; v < MC_MAXV; v++)
-                        if (ctx.vir[h][v] >= 0) {
-                            const int rc_t = ensure_htail(e, &e->irs[ctx.vir[h][v]]);
-                            if (rc_t != MC_OK) return rc_t;
-                        }
+        {
+            const int rc_t = prepare_drop_fft(e, ctx.vir, ctx.predelay);
+            if (rc_t != MC_OK) return rc_t;
         }
         const bool piped = e->pipelined && !lin_sum && !publish;
         hipStream_t ps = e->stream;
@@ -1640,8 +1664,8 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         const int post_first = lin_slice ? lin_first : ctx.first;
         const int post_count = lin_slice ? lin_count : (ctx.out_from >= 0 ? ctx.out_from : ctx.count);
         TailDrop td = td_;
-        if (post_count > 0 && td.on && td.fft) {
-            if (!e->d_dropbuf) HIP_TRY(hipMalloc(&e->d_dropbuf, sizeof(float2) * (size_t)e->Tmax * MC_B));  // (first batch in the regime)
+        if (post_count > 0 && td.on && td.fft && ctx.drop_done) td.dropbuf = e->d_dropbuf;  // (whole batch, indexed from block 0: post_first is 0 then)
+        else if (post_count > 0 && td.on && td.fft) {
             hipLaunchKernelGGL(k_drop_fft, dim3((post_count + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, ps, td, e->d_dropbuf, (int64_t)ctx.t0, post_first,
                                post_count, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
             td.dropbuf = e->d_dropbuf;
@@ -2743,6 +2767,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gm = std::getenv("MCCONV_G2_PMIN")) e->g2_pmin = std::max(16, std::atoi(gm));
     if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
+    if (const char* fo = std::getenv("MCCONV_FUSE_DROP")) e->fuse_drop = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
