@@ -1834,6 +1834,120 @@ __global__ __launch_bounds__(256) void k_drop_period(TailDrop td, float* __restr
     }
 }
 
+// The same period's terms in the frequency domain (the sum of k_drop_fft, one wave per block of the period: a period is too few
+// blocks for whole-line reads of the delay line to matter, the round trips do): per kappa one request of the gains, the four rows
+// of bins and their spectra together per partition, one inverse transform, one slice.  PM waves.
+template <int PM>
+__global__ __launch_bounds__(64 * PM) void k_drop_period_fft(TailDrop td, float* __restrict__ drop, int64_t tabs0, int64_t pd, int64_t n_ref, int64_t blo) {
+    __shared__ float2 s_tw[FFT_N];
+    __shared__ __align__(16) float2 s_fft[PM][FFT_WAVE_LDS];
+    load_twiddles(s_tw, td.g_tw);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2* lds = s_fft[wave];
+    float4* ybin = reinterpret_cast<float4*>(lds);  // [256] {Y_L, Y_R} per bin, before the transform reuses the memory
+    const int64_t b = tabs0 + wave;
+    const int a = (int)(pd >> 8), c = (int)(pd & 255);
+    float dl[4] = {0.f, 0.f, 0.f, 0.f}, dr[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t v_own = (b << 8) - n_ref;
+    if (v_own >= 0) {  // (wave-uniform; nothing below involves another wave)
+        const int dmin = (int)(b - (((v_own >> 8) / PM + 1) * PM - 1));
+#pragma unroll 1
+        for (int kappa = 0; kappa < 3; kappa++) {
+            if (kappa == 2 && c == 0) break;
+            const int p_lo = max(dmin - a - kappa, 0);
+            float4 y[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) y[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool any = false;
+#pragma unroll 1
+            for (int vi = 0; vi < td.nv; vi++) {
+                const int P0 = td.P0[vi], P1 = td.P1[vi], pmax = max(P0, P1);
+                const float4* __restrict__ sg = td.slotgain + (size_t)vi * td.ring;
+#pragma unroll 1
+                for (int p = p_lo; p < pmax; p++) {
+                    const int64_t t = b - kappa - a - p;
+                    if (t < blo || t < 0) break;
+                    any = true;
+                    const unsigned slot = (unsigned)t & (unsigned)(td.ring - 1);
+                    const bool t0 = td.Ht0[vi] && p >= td.tp0[vi], t1 = td.Ht1[vi] && p >= td.tp1[vi];
+                    const float4* __restrict__ B0 = t0 ? td.Ht0[vi] + (size_t)(p - td.tp0[vi]) * MC_NB : td.H0s[vi] + p;
+                    const float4* __restrict__ B1 = t1 ? td.Ht1[vi] + (size_t)(p - td.tp1[vi]) * MC_NB : td.H1s[vi] + p;
+                    const unsigned s0 = t0 ? 1u : (unsigned)td.pstride_ir, s1 = t1 ? 1u : (unsigned)td.pstride_ir;
+                    float4 g = sg[slot];
+                    float4 x[4], h0[4], h1[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const unsigned k = (unsigned)lane + 64u * rr;
+                        x[rr] = td.fdl[k * (unsigned)td.ring + slot];
+                        h0[rr] = B0[k * s0];
+                        h1[rr] = B1[k * s1];
+                    }
+                    g.x = p < P0 ? g.x : 0.f, g.z = p < P0 ? g.z : 0.f;
+                    g.y = p < P1 ? g.y : 0.f, g.w = p < P1 ? g.w : 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                        cmac<false>(a0, h0[rr].x, h0[rr].y, x[rr].x, x[rr].y);
+                        cmac<false>(a1, h1[rr].x, h1[rr].y, x[rr].z, x[rr].w);
+                        cmac<false>(a2, h0[rr].z, h0[rr].w, x[rr].x, x[rr].y);
+                        cmac<false>(a3, h1[rr].z, h1[rr].w, x[rr].z, x[rr].w);
+                        if (rr == 0 && lane == 0) {  // bin 0 packs {DC, Nyquist}: two real products
+                            a0 = make_float2(h0[0].x * x[0].x, h0[0].y * x[0].y);
+                            a1 = make_float2(h1[0].x * x[0].z, h1[0].y * x[0].w);
+                            a2 = make_float2(h0[0].z * x[0].x, h0[0].w * x[0].y);
+                            a3 = make_float2(h1[0].z * x[0].z, h1[0].w * x[0].w);
+                        }
+                        y[rr].x += g.x * a0.x + g.y * a1.x;
+                        y[rr].y += g.x * a0.y + g.y * a1.y;
+                        y[rr].z += g.z * a2.x + g.w * a3.x;
+                        y[rr].w += g.z * a2.y + g.w * a3.y;
+                    }
+                }
+            }
+            if (!any) continue;  // (wave-uniform)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) ybin[lane + 64 * rr] = y[rr];
+            fft_sync<false>();
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {  // Hermitian extension of the packed spectrum Y_L + j Y_R (as k_inv)
+                const int n = lane + 64 * r;
+                float2 w;
+                if (n == 0) {
+                    const float4 yy = ybin[0];
+                    w = make_float2(yy.x, yy.z);
+                } else if (n == MC_B) {
+                    const float4 yy = ybin[0];
+                    w = make_float2(yy.y, yy.w);
+                } else if (n < MC_B) {
+                    const float4 yy = ybin[n];
+                    w = make_float2(yy.x - yy.w, yy.y + yy.z);
+                } else {
+                    const float4 yy = ybin[FFT_N - n];
+                    w = make_float2(yy.x + yy.w, -yy.y + yy.z);
+                }
+                v[r] = w;
+            }
+            fft_sync<false>();
+            fft512_wave<+1, false>(v, lds, s_tw, lane);
+            const float sc = 1.0f / FFT_N;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 256 * kappa + 4 * lane + q - c;  // segment index of frame r = 4 lane + q
+                if (i >= 0 && i < FFT_N) {
+                    const float2 z = lds[i];
+                    dl[q] += z.x * sc;
+                    dr[q] += z.y * sc;
+                }
+            }
+            fft_sync<false>();
+        }
+    }
+    *reinterpret_cast<float4*>(drop + wave * MC_B + 4 * lane) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+    *reinterpret_cast<float4*>(drop + PM * MC_B + wave * MC_B + 4 * lane) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+}
+
 // ---------------------------------------------------------------------------
 // K6: overlap-add + predelay + Q1/Q2 window sums + Q8 + saturating clamp + dry
 // mix (replaces f_pointwiseAdd, f_addDryInterleaved and the residual slide,

@@ -853,6 +853,15 @@ const float* launch_drop_period(mc_engine* e, const TailDrop& td, uint64_t blk, 
     if (!td.on) return nullptr;
     float* dst = e->d_drop[(blk / (uint64_t)e->pm) & 1];
     const int64_t blo = (int64_t)e->epoch_b0;
+    if (td.fft) {  // in the frequency domain: a partition sum over the last partitions and one inverse transform per block (k_drop_period_fft)
+        if (e->pm == 1)
+            hipLaunchKernelGGL(k_drop_period_fft<1>, dim3(1), dim3(64), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, blo);
+        else if (e->pm == 2)
+            hipLaunchKernelGGL(k_drop_period_fft<2>, dim3(1), dim3(128), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, blo);
+        else
+            hipLaunchKernelGGL(k_drop_period_fft<4>, dim3(1), dim3(256), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, blo);
+        return dst;
+    }
     if (e->pm == 1)
         hipLaunchKernelGGL(k_drop_period<1>, dim3(1), dim3(256), 0, e->stream, td, dst, (int64_t)blk, (int64_t)predelay, (int64_t)e->cfg.n_ref, e->rc, blo);
     else if (e->pm == 2)
@@ -1915,6 +1924,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.outL = e->hd_io + 2 * cap;
         A.outR = e->hd_io + 3 * cap;
         A.g_tw = e->d_tw;
+        (void)prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);  // (Q8 regime: the last partitions partition-major; without them the bank is read)
         A.td = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
         A.fdl16 = e->d_fdl16;
         A.done_flag = e->hd_flag;
@@ -2370,6 +2380,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
     auto launch_tail = [&](const Staged& st, const PPlan& pl, uint64_t blk, unsigned seq, bool parked) {
         const int slot0 = (int)(blk & (uint64_t)(e->ring - 1));
         const unsigned long long* bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
+        (void)prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
         const TailDrop tdp = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
         const float* drop = launch_drop_period(e, tdp, blk, st.ctx.predelay);
 #define MC_LAUNCH_TAILP(PM)                                                                                                  \
