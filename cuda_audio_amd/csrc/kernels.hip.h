@@ -2671,6 +2671,9 @@ __global__ __launch_bounds__(256) void k_jack(TailArgs A, SweepArgs S) {
 // cross-fade once per call) and the Q1/Q2/Q8 windows start at the call.
 // ---------------------------------------------------------------------------
 template <int PM>
+#ifdef TAILP_VGPR_CAP  // (measurement build: DESIGN section 4, JACK path, item 3)
+__attribute__((amdgpu_num_vgpr(TAILP_VGPR_CAP)))
+#endif
 __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, const float* __restrict__ in2, VoiceSet vset,
                                                int pstride_ir, float4* __restrict__ fdl, float4* __restrict__ slotgain, int ring,
                                                int slot0, const float4* __restrict__ part, int nsum,
