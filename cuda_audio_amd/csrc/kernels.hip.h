@@ -68,6 +68,34 @@ struct VoiceSums {
     double alp[MC_MAXV][2][2];
 };
 
+// acc += h * x for complex h, x (PACKED: bin 0 packs {DC, Nyquist}: two real products)
+template <bool PACKED>
+__device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, float xy) {
+    if (PACKED) {
+        acc.x = fmaf(hx, xx, acc.x);
+        acc.y = fmaf(hy, xy, acc.y);
+    } else {
+        acc.x = fmaf(hx, xx, acc.x);
+        acc.x = fmaf(-hy, xy, acc.x);
+        acc.y = fmaf(hx, xy, acc.y);
+        acc.y = fmaf(hy, xx, acc.y);
+    }
+}
+
+// Q8 regime, whole batches, when every output block's cut terms are ONE (kappa, partition) term of ONE source block (the reference's
+// shipped operating point: predelay 1024, an IR of n_ref - 1024 frames): the wave that has just transformed block t holds all that
+// term needs - X_t in registers, the block's gains, one partition of the voices' spectra - and sums the cut terms of output block
+// t + shift on the spot (product, inverse transform, slice: what k_drop_fft does, minus its 4 KB read of the delay line per block and
+// a launch that is bound by its round trips).  Output blocks whose source lies before the batch stay with k_drop_fft.
+struct DropAhead {
+    int shift;                   // output block = source block + shift (kappa + predelay / 256 + partition)
+    int kappa, c;                // slice of the segment: index 256 kappa + frame - c
+    int nv;
+    const float4* Ht0[MC_MAXV];  // the term's partition of voice v's IR for input 1, [256 bins] {H_L, H_R} (null: the IR has no such partition)
+    const float4* Ht1[MC_MAXV];
+    float2* drop;                // [T][256] {L, R} of the batch's output blocks
+};
+
 // ---------------------------------------------------------------------------
 // K1: forward transform of T input blocks -> delay-line slots (raw spectra).
 // Replaces f_pack2R2C + memset + cufftExecC2C + f_unpackC22R (conv.cu:35-73,
@@ -76,6 +104,8 @@ struct VoiceSums {
 // are the two "inputs", slot = partition index.
 // grid = ceil(T / 8), block = 256 (4 waves x 2 transforms each).
 // ---------------------------------------------------------------------------
+template <bool DA>
+__attribute__((amdgpu_waves_per_eu(DA ? 6 : 1, DA ? 6 : 8)))  // DA: 80 registers (7 spilled) keep three workgroups on a CU: 281 against 330 us per 130 000 blocks at 122
 __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in1, const float* __restrict__ in2,
                                              int in_stride,     // floats between successive frames (1, or 2 for interleaved IR)
                                              int64_t n_frames,  // valid frames in in1/in2 (zero beyond)
@@ -90,7 +120,8 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
                                              int64_t tabs0,                       // absolute block of t = 0
                                              int need_a0, int need_a1, int need_b0,
                                              int hist_from,  // input history is kept from this block on (see run_front)
-                                             int t_base) {   // first block of this launch (a block-sliced rank launches its ranges)
+                                             int t_base,     // first block of this launch (a block-sliced rank launches its ranges)
+                                             DropAhead da) { // DA: the cut terms of output block t + da.shift (see DropAhead)
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
@@ -173,6 +204,81 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
             const float* gv = ptab[(int64_t)t * pstride].g[lane];
             slotgain[(size_t)lane * ring + ((slot0 + t) & (ring - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
             if (gring) gring[(size_t)lane * rc + (size_t)((tabs0 + t) & (rc - 1))] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+        if (DA && t + da.shift < T) {  // (wave-uniform) the arithmetic of k_drop_fft's single term, in its order
+            const BlockParams& bp = ptab[(int64_t)t * pstride];
+            float4 y[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) y[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int vi = 0; vi < MC_MAXV; vi++) {
+                if (vi >= da.nv || (!da.Ht0[vi] && !da.Ht1[vi])) continue;
+                const float4* __restrict__ B0 = da.Ht0[vi] ? da.Ht0[vi] : da.Ht1[vi];
+                const float4* __restrict__ B1 = da.Ht1[vi] ? da.Ht1[vi] : da.Ht0[vi];
+                float4 g = make_float4(bp.g[vi][0], bp.g[vi][1], bp.g[vi][2], bp.g[vi][3]);
+                g.x = da.Ht0[vi] ? g.x : 0.f, g.z = da.Ht0[vi] ? g.z : 0.f;
+                g.y = da.Ht1[vi] ? g.y : 0.f, g.w = da.Ht1[vi] ? g.w : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = lane + 64 * j;
+                    const float4 h0 = B0[k], h1 = B1[k], x = xs[j];
+                    float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+                    cmac<false>(a0, h0.x, h0.y, x.x, x.y);
+                    cmac<false>(a1, h1.x, h1.y, x.z, x.w);
+                    cmac<false>(a2, h0.z, h0.w, x.x, x.y);
+                    cmac<false>(a3, h1.z, h1.w, x.z, x.w);
+                    if (j == 0 && lane == 0) {  // bin 0 packs {DC, Nyquist}: two real products
+                        a0 = make_float2(h0.x * x.x, h0.y * x.y);
+                        a1 = make_float2(h1.x * x.z, h1.y * x.w);
+                        a2 = make_float2(h0.z * x.x, h0.w * x.y);
+                        a3 = make_float2(h1.z * x.z, h1.w * x.w);
+                    }
+                    y[j].x += g.x * a0.x + g.y * a1.x;
+                    y[j].y += g.x * a0.y + g.y * a1.y;
+                    y[j].z += g.z * a2.x + g.w * a3.x;
+                    y[j].w += g.z * a2.y + g.w * a3.y;
+                }
+            }
+            float4* ybin = reinterpret_cast<float4*>(lds);  // [256] {Y_L, Y_R} per bin (the forward transform's buffer: every lane has read its spectrum)
+            fft_sync<false>();
+#pragma unroll
+            for (int j = 0; j < 4; j++) ybin[lane + 64 * j] = y[j];
+            fft_sync<false>();
+            float2 w8[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {  // Hermitian extension of the packed spectrum Y_L + j Y_R (as k_inv)
+                const int n = lane + 64 * r;
+                float2 w;
+                if (n == 0) {
+                    const float4 yy = ybin[0];
+                    w = make_float2(yy.x, yy.z);
+                } else if (n == MC_B) {
+                    const float4 yy = ybin[0];
+                    w = make_float2(yy.y, yy.w);
+                } else if (n < MC_B) {
+                    const float4 yy = ybin[n];
+                    w = make_float2(yy.x - yy.w, yy.y + yy.z);
+                } else {
+                    const float4 yy = ybin[FFT_N - n];
+                    w = make_float2(yy.x + yy.w, -yy.y + yy.z);
+                }
+                w8[r] = w;
+            }
+            fft_sync<false>();
+            fft512_wave<+1, false>(w8, lds, s_tw, lane);
+            const float sc = 1.0f / FFT_N;
+            float dl[4], dr[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 256 * da.kappa + 4 * lane + q - da.c;  // segment index of frame 4 lane + q
+                const bool in = i >= 0 && i < FFT_N;
+                const float2 z = lds[in ? i : 0];
+                dl[q] = in ? z.x * sc : 0.f;
+                dr[q] = in ? z.y * sc : 0.f;
+            }
+            float4* dst = reinterpret_cast<float4*>(da.drop + (size_t)(t + da.shift) * MC_B + 4 * lane);
+            dst[0] = make_float4(dl[0], dr[0], dl[1], dr[1]);
+            dst[1] = make_float4(dl[2], dr[2], dl[3], dr[3]);
         }
     }
     __syncthreads();  // every wave has read its transform: the buffers become the tile
@@ -265,18 +371,6 @@ __global__ __launch_bounds__(256) void k_mix(float* __restrict__ dst, size_t n, 
 // holds two independent real bins {DC, Nyquist}.
 // (replaces f_pointwiseMultiplyAndScale, conv.cu:102-123, with the true product; Q3)
 // ---------------------------------------------------------------------------
-template <bool PACKED>
-__device__ __forceinline__ void cmac(float2& acc, float hx, float hy, float xx, float xy) {
-    if (PACKED) {
-        acc.x = fmaf(hx, xx, acc.x);
-        acc.y = fmaf(hy, xy, acc.y);
-    } else {
-        acc.x = fmaf(hx, xx, acc.x);
-        acc.x = fmaf(-hy, xy, acc.x);
-        acc.y = fmaf(hx, xy, acc.y);
-        acc.y = fmaf(hy, xx, acc.y);
-    }
-}
 
 // ---------------------------------------------------------------------------
 // K2 (batch): partition x bin complex MAC with the IR held on chip.

@@ -273,6 +273,7 @@ struct mc_engine {
     unsigned* hd_exited = nullptr;
     // how often a parked period was used / gave up on its own (host away > park_ms) / was told to give up: mc_debug_read item 6
     uint64_t n_park_hit = 0, n_park_timeout = 0, n_park_cancel = 0;
+    uint64_t n_drop_fft = 0, n_drop_ahead = 0, n_drop_tiles = 0;  // Q8 regime: batches by the form their cut terms took (mc_debug_read item 9)
 #ifdef MC_JACK_TRACE
     double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0;
     unsigned long long tr_prev_end = 0;
@@ -289,6 +290,7 @@ struct mc_engine {
     int g2_pmin = 16;        // shortest block-axis convolution (partitions, uniform gains) of an unsharded engine that takes the
                              // second-level transform (MCCONV_G2_PMIN; round 1: 256)
     bool corr_ride = true;   // MCCONV_CORR_RIDE=0: the Q1/Q2 prefix steps as launches of their own (measurement)
+    bool drop_ahead = true;  // MCCONV_DROP_AHEAD=0: Q8 regime: every cut term through k_drop_fft, none summed by the forward transforms (measurement)
     bool fuse_drop = true;   // MCCONV_FUSE_DROP=0: Q8 regime: the output through k_post<3> even where the inverse transforms could finish it (measurement)
     bool fuse_out = true;    // MCCONV_FUSE_OUT=0: the output always through k_post (measurement)
     unsigned* d_cticket = nullptr;  // ticket counter of the riding prefix-sum workgroups (see CorrArgs)
@@ -847,6 +849,40 @@ int prepare_drop_fft(mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_t predel
     return MC_OK;
 }
 
+// Whether every output block of a batch (calls of one block) loses exactly ONE (kappa, partition) term, the same for every voice that
+// loses anything - then k_fwd<true> sums the cut terms (DropAhead).  The terms of block b: kappa in {0, 1, 2 if predelay % 256},
+// partitions p >= n_ref / 256 - predelay / 256 - kappa of every voice's IRs (k_drop_fft).
+int plan_drop_ahead(mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_t predelay, DropAhead* da, int* shift) {
+    *shift = -1;
+    int rc = prepare_drop_fft(e, vir, predelay);
+    if (rc != MC_OK) return rc;
+    const TailDrop td = make_taildrop(e, vir, predelay);
+    if (!td.on || !td.fft || !e->d_dropbuf) return MC_OK;
+    const int N = (int)(e->cfg.n_ref / MC_B), a = (int)(predelay >> 8), c = (int)(predelay & 255);
+    int kap = -1, part = -1;
+    for (int v = 0; v < td.nv; v++) {
+        const int pmax = std::max(td.P0[v], td.P1[v]);
+        for (int kappa = 0; kappa < (c ? 3 : 2); kappa++)
+            for (int p = std::max(N - a - kappa, 0); p < pmax; p++) {
+                if (kap >= 0 && (kap != kappa || part != p)) return MC_OK;  // a second term
+                kap = kappa, part = p;
+            }
+    }
+    if (kap < 0) return MC_OK;
+    for (int v = 0; v < td.nv; v++) {
+        da->Ht0[v] = part < td.P0[v] ? (td.Ht0[v] && part >= td.tp0[v] ? td.Ht0[v] + (size_t)(part - td.tp0[v]) * MC_NB : nullptr) : nullptr;
+        da->Ht1[v] = part < td.P1[v] ? (td.Ht1[v] && part >= td.tp1[v] ? td.Ht1[v] + (size_t)(part - td.tp1[v]) * MC_NB : nullptr) : nullptr;
+        if ((part < td.P0[v] && !da->Ht0[v]) || (part < td.P1[v] && !da->Ht1[v])) return MC_OK;  // (no partition-major copy: k_drop_fft reads the bank)
+    }
+    da->nv = td.nv;
+    da->kappa = kap;
+    da->c = c;
+    da->shift = kap + a + part;
+    da->drop = e->d_dropbuf;
+    *shift = da->shift;
+    return MC_OK;
+}
+
 // JACK path in the Q8 regime: the tail-drop terms of the period that starts at block blk (pm blocks), ahead of its tail kernel
 // on the engine's stream (they depend on blocks at least n_ref frames old only).  Returns the buffer the tail reads, or null.
 const float* launch_drop_period(mc_engine* e, const TailDrop& td, uint64_t blk, uint64_t predelay) {
@@ -1306,10 +1342,10 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         if (!(Tc >= e->stream_threshold && !e->half)) Tc = std::min(Tc, e->Tstream);
         const int slot0 = (int)(tv & (uint64_t)(e->ring - 1));
         // silent blocks into the delay line (n_frames = 0: the inputs are never read)
-        hipLaunchKernelGGL(k_fwd, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
+        hipLaunchKernelGGL(k_fwd<false>, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
-                           (int64_t)0, 0, Tc, Tc, 0, 0);
+                           (int64_t)0, 0, Tc, Tc, 0, 0, DropAhead());
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
@@ -1444,16 +1480,26 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     // LATER calls (a batch reads its own samples from its input buffers): they look back less than one reference
     // length + the largest predelay, so a long batch keeps only its tail.
     const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
+    DropAhead da;
+    std::memset(&da, 0, sizeof(da));
+    int da_shift = -1;
     {
         // one launch per run of needed blocks (a whole-batch call: one launch over everything)
         int lo[2] = {need_a0 & ~(FWD_TILE - 1), need_b0 & ~(FWD_TILE - 1)}, hi[2] = {need_a1, T};
         if (lo[1] <= hi[0]) hi[0] = T, lo[1] = T;  // the two runs meet
+        // Q8 regime, a whole batch whose output blocks each lose ONE term of ONE source block: the forward transforms sum the cut terms
+        // themselves (DropAhead; da_shift = -1 otherwise and k_drop_fft sums them all)
+        if (!slice && !lin && to_wet && !e->pipelined && e->fuse_out && e->fuse_drop && e->drop_ahead && e->pm == 1 && first == 0 && count == T &&
+            e->res_end <= e->t_front * MC_B && e->epoch_b0 <= e->t_front && hi[0] == T && lo[0] == 0) {
+            const int rc_t = plan_drop_ahead(e, st.ctx.vir, st.ctx.predelay, &da, &da_shift);
+            if (rc_t != MC_OK) return rc_t;
+        }
         for (int r = 0; r < 2; r++)
             if (hi[r] > lo[r])
-                hipLaunchKernelGGL(k_fwd, dim3((hi[r] - lo[r] + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
+                hipLaunchKernelGGL(da_shift >= 0 ? k_fwd<true> : k_fwd<false>, dim3((hi[r] - lo[r] + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
                                    (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw,
                                    e->d_fdl16, e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0,
-                                   hist_from, lo[r]);
+                                   hist_from, lo[r], da);
     }
     if (e->ktiming && e->kev_n == kEvPool) {
         int rc = drain_kernel_events(e);
@@ -1550,7 +1596,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                     const int rc_t = prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
                     if (rc_t != MC_OK) return rc_t;
                     tdq = make_taildrop(e, st.ctx.vir, st.ctx.predelay);  // (with the partition-major spectra)
-                    hipLaunchKernelGGL(k_drop_fft, dim3((T + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, inv_stream, tdq, e->d_dropbuf, (int64_t)st.ctx.t0, 0, T,
+                    const int nd = da_shift >= 0 ? std::min(T, da_shift) : T;  // (the forward transforms summed the blocks from da_shift on)
+                    (da_shift >= 0 && da_shift < T ? e->n_drop_ahead : e->n_drop_fft)++;
+                    hipLaunchKernelGGL(k_drop_fft, dim3((nd + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, inv_stream, tdq, e->d_dropbuf, (int64_t)st.ctx.t0, 0, nd,
                                        (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
                     stored.drop_done = true;
                 }
@@ -1675,10 +1723,12 @@ int run_back(mc_engine* e, const float* d_in1, const float* d_in2, const float* 
         TailDrop td = td_;
         if (post_count > 0 && td.on && td.fft && ctx.drop_done) td.dropbuf = e->d_dropbuf;  // (whole batch, indexed from block 0: post_first is 0 then)
         else if (post_count > 0 && td.on && td.fft) {
+            e->n_drop_fft++;
             hipLaunchKernelGGL(k_drop_fft, dim3((post_count + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, ps, td, e->d_dropbuf, (int64_t)ctx.t0, post_first,
                                post_count, (int64_t)ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
             td.dropbuf = e->d_dropbuf;
         }
+        if (post_count > 0 && td.on && !td.fft) e->n_drop_tiles++;
         if (post_count > 0)
         hipLaunchKernelGGL(td.on ? (td.fft ? k_post<3> : k_post<1>) : k_post<0>, dim3((post_count + 3) / 4), dim3(256), 0, ps, ctx.wet_ready ? (const float*)nullptr : e->d_seg, e->sr,
                            lin_sum, e->d_wet, e->wr, e->d_cring,
@@ -2779,6 +2829,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
     if (const char* fo = std::getenv("MCCONV_FUSE_DROP")) e->fuse_drop = std::atoi(fo) != 0;
+    if (const char* fo = std::getenv("MCCONV_DROP_AHEAD")) e->drop_ahead = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
@@ -2934,9 +2985,9 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     hipError_t er = hipMemcpy(d_lr, lr, sizeof(float) * 2 * n, hipMemcpyHostToDevice);
     if (er == hipSuccess) er = hipMemsetAsync(ir.d_H, 0, sizeof(float4) * (size_t)MC_NB * e->Pstride, e->stream);
     if (er == hipSuccess) {
-        hipLaunchKernelGGL(k_fwd, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
+        hipLaunchKernelGGL(k_fwd<false>, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
-                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0, 0);
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0, 0, DropAhead());
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
@@ -3274,6 +3325,12 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         const uint64_t g = which == 7 ? e->last_gen : e->ph.sample(cc);
         if (off + bytes > sizeof(uint64_t)) return fail(MC_ERR_ARG, "read beyond the generation word");
         std::memcpy(dst, reinterpret_cast<const char*>(&g) + off, bytes);
+        return MC_OK;
+    }
+    if (which == 9) {  // Q8 regime, batches: {cut terms summed by k_drop_fft for the whole batch, by the forward transforms (k_fwd<true>), in the time domain}: no stream access
+        const uint64_t c[3] = {e->n_drop_fft, e->n_drop_ahead, e->n_drop_tiles};
+        if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
+        std::memcpy(dst, reinterpret_cast<const char*>(c) + off, bytes);
         return MC_OK;
     }
     if (which == 6) {  // host-side counters of the JACK path's parked periods {used, gave up on their own, told to give up}: no stream access

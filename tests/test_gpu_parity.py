@@ -532,17 +532,22 @@ def test_q8_history_across_long_batches(oracle_mod, gpu_lib, sizes):
     c.close()
 
 
-@pytest.mark.parametrize("period,form", [(256, "fft"), (512, "fft"), (1024, "fft"), (512, "tiles")])
-def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period, form, monkeypatch):
+@pytest.mark.parametrize("period,form,pd", [(256, "fft", 1100), (512, "fft", 1100), (1024, "fft", 1100), (512, "tiles", 1100), (256, "fft", 1024),
+                                            (256, "no_drop_ahead", 1024)])
+def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period, form, pd, monkeypatch):
     """The Q8 regime with everything that shapes its cut terms at once: two IRs of different length cross-fading on one half
     (two voices with their own gains per block), an unaligned predelay (three slices of the last partitions' segments
     contribute), and reference calls of 2 and 4 blocks (the cut is measured from the start of the CALL: block distances
-    differ inside a call).  Batches of whole calls, both forms of the cut terms, against oracle.RefCompat run call by call."""
+    differ inside a call).  Batches of whole calls, both forms of the cut terms, against oracle.RefCompat run call by call.
+    Predelay 1024 with calls of one block is the shipped shape - every output block loses ONE term of ONE source block, here of two
+    cross-fading voices with gains per block - which the forward transforms sum themselves (k_fwd<true>; `no_drop_ahead`: k_drop_fft)."""
     from cuda_audio_amd.synth import make_input
 
     if form == "tiles":
         monkeypatch.setenv("MCCONV_TD_FFT", "0")
-    n_ref, pd, pm = 4096, 1100, period // 256
+    if form == "no_drop_ahead":
+        monkeypatch.setenv("MCCONV_DROP_AHEAD", "0")
+    n_ref, pm = 4096, period // 256
     ncalls = (3 * n_ref // 256 // 2 + 44) // pm
     x = make_input(ncalls * period, seed=91)
     rng = np.random.default_rng(17)
@@ -552,7 +557,8 @@ def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period,
         irs.append((h * np.sqrt(0.004 / L)).astype(np.float32))
     p0, p1 = dict(BASE, predelay=pd, speed=9), dict(BASE, select=1, level=0.9, speed=14)
     ref = oracle_mod.RefCompat(n_ref, True)
-    c = _conv(fftSize=n_ref, max_batch=6 * pm, period=period)
+    per = 6 if pd != 1024 else 30  # (calls per batch; the one-term shape needs batches longer than its 16 blocks of reach)
+    c = _conv(fftSize=n_ref, max_batch=per * pm, period=period)
     for i, ir in enumerate(irs):
         ref.prepare(i, ir)
         c.prepare(i, ir)
@@ -567,14 +573,22 @@ def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period,
             half, ir = switches[k]
             ref.set(half, select=ir, vsteps=(p0, p1)[half]["speed"])
             c.cc[half].value.update(select=ir, vsteps=(p0, p1)[half]["speed"])
-        n = min(5, ncalls - k, min([q for q in switches if q > k] + [ncalls]) - k)
+        n = min(per - 1, ncalls - k, min([q for q in switches if q > k] + [ncalls]) - k)
         s = slice(k * period, (k + n) * period)
         want[:, s] = ref.process(x[0, s], x[1, s], block=period)
         got[:, s] = c.process(x[0, s], x[1, s])
         k += n
+    stats = c.drop_stats()
     c.close()
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    # the form under test is the form that ran
+    if form == "tiles":
+        assert stats["tiles"] > 0 and stats["drop_fft"] == stats["forward_transforms"] == 0, stats
+    elif form == "fft" and pd == 1024:
+        assert stats["forward_transforms"] > 0 and stats["tiles"] == 0, stats
+    else:
+        assert stats["drop_fft"] > 0 and stats["forward_transforms"] == stats["tiles"] == 0, stats
 
 
 @pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
