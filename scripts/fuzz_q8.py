@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised runs in and around the Q8 regime against oracle.RefCompat (GPU box; not part of the test suite: minutes of oracle time).
+Every run: random IR lengths up to n_ref - 1024 (several exactly there: the shipped shape), random controller traffic (select, predelay
+- often back to 1024 -, wet, speed, pans, level), and a random mix of batches (up to 64 blocks: longer than the reach of the cut terms, so the
+forward transforms sum them where the shape allows) and single periods.  usage: fuzz_q8.py [first_seed] [runs]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as oracle_mod  # noqa: E402
+from cuda_audio_amd.engine import Convolution  # noqa: E402
+from cuda_audio_amd.synth import make_input  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+TOL = 1e-5
+cmap = (21, 22, 23, 24, 25, 26, 27, 28)
+arr = (C.c_uint8 * 8)(*cmap)
+bad = 0
+tot = dict(drop_fft=0, forward_transforms=0, tiles=0)
+for seed in range(first, first + runs):
+    rng = np.random.default_rng(seed)
+    n_ref = int(rng.choice([4096, 8192]))
+    nb = 6 * n_ref // 256 + 200
+    nirs = int(rng.integers(2, 5))
+    full = n_ref - 1024
+    lens = [full if rng.random() < 0.6 else int(rng.integers(full // 2, full + 1)) for _ in range(nirs)]
+    irs = []
+    for L in lens:
+        h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (1.5 * L))[:, None]
+        irs.append((h * np.sqrt(0.003 / L)).astype(np.float32))
+    x = make_input(nb * 256, seed=100 + seed)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = Convolution("fuzz", n_ref, max_batch=64, stream_threshold=8)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    # start at the shipped predelay (controller value 16 -> 1024 frames)
+    for half in (0, 1):
+        oracle_mod.handle_cc(ref.cc(half), cmap, 22, 16, ref.num_irs())
+        assert c._L.mc_handle_cc(c._h, half, arr, 22, 16) == 0
+    events, q = {}, int(rng.integers(20, 60))
+    while q < nb:
+        ctl = int(rng.choice(cmap))
+        val = int(rng.integers(0, 128))
+        if ctl == 22:
+            val = 16 if rng.random() < 0.5 else int(rng.integers(0, 128))
+        if ctl == 25:
+            val = int(rng.integers(0, 4))
+        if ctl == 28:
+            val = int(rng.integers(64, 128))
+        events.setdefault(q, []).append((int(rng.integers(0, 2)), ctl, val))
+        q += int(rng.integers(3, 45))
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    q = 0
+    while q < nb:
+        for half, ctl, val in events.get(q, []):
+            oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
+            assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
+        nxt = min([e for e in events if e > q] + [nb])
+        n = 1 if rng.random() < 0.25 else int(min(rng.integers(2, 65), nxt - q))
+        s = slice(q * 256, (q + n) * 256)
+        for k in range(n):
+            ss = slice((q + k) * 256, (q + k + 1) * 256)
+            want[:, ss] = ref.process(x[0, ss], x[1, ss])
+        if n == 1:
+            got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+        else:
+            got[:, s] = c.process(x[0, s], x[1, s])
+        q += n
+    st = c.drop_stats()
+    c.close()
+    for k in tot:
+        tot[k] += st[k]
+    err = float(np.sqrt(np.mean((got - want) ** 2)))
+    flag = "" if err <= TOL else "   <-- FAIL"
+    bad += err > TOL
+    print(f"seed {seed}: n_ref {n_ref}, IRs {lens}, {len(events)} event calls, rms {err:.3e} (signal {np.sqrt(np.mean(want ** 2)):.3e}, peak {np.abs(want).max():.2f}) {st}{flag}", flush=True)
+print(f"{runs} runs, {bad} above {TOL}; batches by form of the cut terms: {tot}")
+sys.exit(1 if bad else 0)
