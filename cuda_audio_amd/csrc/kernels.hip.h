@@ -1694,7 +1694,9 @@ __global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(D
                 const int64_t t = b_s - kappa - a - p;
                 const bool ok = act_s && p >= p_lo && t >= blo && t >= 0;
                 const unsigned slot = (unsigned)(t < 0 ? 0 : t) & (unsigned)(td.ring - 1);
-                const bool t0 = td.Ht0[vi] && p >= td.tp0[vi], t1 = td.Ht1[vi] && p >= td.tp1[vi];  // (uniform)
+                // (uniform) the partition-major copy holds partitions [tp, P) of its IR and nothing beyond: the loads below are unconditional, so
+                // a partition the other input's longer IR still has is read from the bank, which is zero there (its gains are zero too)
+                const bool t0 = td.Ht0[vi] && p >= td.tp0[vi] && p < P0, t1 = td.Ht1[vi] && p >= td.tp1[vi] && p < P1;
                 const float4* __restrict__ B0 = t0 ? td.Ht0[vi] + (size_t)(p - td.tp0[vi]) * MC_NB : td.H0s[vi] + p;
                 const float4* __restrict__ B1 = t1 ? td.Ht1[vi] + (size_t)(p - td.tp1[vi]) * MC_NB : td.H1s[vi] + p;
                 const unsigned s0 = t0 ? 1u : (unsigned)td.pstride_ir, s1 = t1 ? 1u : (unsigned)td.pstride_ir;
@@ -1964,7 +1966,7 @@ __global__ __launch_bounds__(64 * PM) void k_drop_period_fft(TailDrop td, float*
                     if (t < blo || t < 0) break;
                     any = true;
                     const unsigned slot = (unsigned)t & (unsigned)(td.ring - 1);
-                    const bool t0 = td.Ht0[vi] && p >= td.tp0[vi], t1 = td.Ht1[vi] && p >= td.tp1[vi];
+                    const bool t0 = td.Ht0[vi] && p >= td.tp0[vi] && p < P0, t1 = td.Ht1[vi] && p >= td.tp1[vi] && p < P1;  // (as k_drop_fft: nothing beyond an IR's last partition in its copy)
                     const float4* __restrict__ B0 = t0 ? td.Ht0[vi] + (size_t)(p - td.tp0[vi]) * MC_NB : td.H0s[vi] + p;
                     const float4* __restrict__ B1 = t1 ? td.Ht1[vi] + (size_t)(p - td.tp1[vi]) * MC_NB : td.H1s[vi] + p;
                     const unsigned s0 = t0 ? 1u : (unsigned)td.pstride_ir, s1 = t1 ? 1u : (unsigned)td.pstride_ir;

@@ -2,7 +2,8 @@
 """Randomised runs in and around the Q8 regime against oracle.RefCompat (GPU box; not part of the test suite: minutes of oracle time).
 Every run: random IR lengths up to n_ref - 1024 (several exactly there: the shipped shape), random controller traffic (select, predelay
 - often back to 1024 -, wet, speed, pans, level), and a random mix of batches (up to 64 blocks: longer than the reach of the cut terms, so the
-forward transforms sum them where the shape allows) and single periods.  usage: fuzz_q8.py [first_seed] [runs]"""
+forward transforms sum them where the shape allows) and single periods.  usage: fuzz_q8.py [first_seed] [runs] [general]
+`general`: also periods of 512 / 1024 frames, up to 7 IRs of any length (more than the engine has voices: they merge), n_ref up to 16384, any predelay."""
 import ctypes as C
 import os
 import sys
@@ -18,6 +19,8 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+general = len(sys.argv) > 3 and sys.argv[3] == "general"
+trace = os.environ.get("FUZZ_TRACE") == "1"  # every call printed before it runs and synchronised after it (fault triage)
 TOL = 1e-5
 cmap = (21, 22, 23, 24, 25, 26, 27, 28)
 arr = (C.c_uint8 * 8)(*cmap)
@@ -25,25 +28,31 @@ bad = 0
 tot = dict(drop_fft=0, forward_transforms=0, tiles=0)
 for seed in range(first, first + runs):
     rng = np.random.default_rng(seed)
-    n_ref = int(rng.choice([4096, 8192]))
-    nb = 6 * n_ref // 256 + 200
-    nirs = int(rng.integers(2, 5))
+    n_ref = int(rng.choice([4096, 8192, 16384] if general else [4096, 8192]))
+    period = int(rng.choice([256, 256, 512, 1024])) if general else 256
+    pm = period // 256
+    nb = (6 * n_ref // 256 + 200) // pm  # calls
+    nirs = int(rng.integers(2, 8 if general else 5))
     full = n_ref - 1024
-    lens = [full if rng.random() < 0.6 else int(rng.integers(full // 2, full + 1)) for _ in range(nirs)]
+    if general:
+        lens = [full if rng.random() < 0.3 else int(rng.integers(300, full + 1)) for _ in range(nirs)]
+    else:
+        lens = [full if rng.random() < 0.6 else int(rng.integers(full // 2, full + 1)) for _ in range(nirs)]
     irs = []
     for L in lens:
         h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (1.5 * L))[:, None]
         irs.append((h * np.sqrt(0.003 / L)).astype(np.float32))
-    x = make_input(nb * 256, seed=100 + seed)
+    x = make_input(nb * period, seed=100 + seed)
     ref = oracle_mod.RefCompat(n_ref, True)
-    c = Convolution("fuzz", n_ref, max_batch=64, stream_threshold=8)
+    c = Convolution("fuzz", n_ref, max_batch=64 * pm, stream_threshold=8, period=period)
     for i, ir in enumerate(irs):
         ref.prepare(i, ir)
         c.prepare(i, ir)
     # start at the shipped predelay (controller value 16 -> 1024 frames)
     for half in (0, 1):
-        oracle_mod.handle_cc(ref.cc(half), cmap, 22, 16, ref.num_irs())
-        assert c._L.mc_handle_cc(c._h, half, arr, 22, 16) == 0
+        pd0 = 16 if not general or rng.random() < 0.5 else int(rng.integers(0, 128))
+        oracle_mod.handle_cc(ref.cc(half), cmap, 22, pd0, ref.num_irs())
+        assert c._L.mc_handle_cc(c._h, half, arr, 22, pd0) == 0
     events, q = {}, int(rng.integers(20, 60))
     while q < nb:
         ctl = int(rng.choice(cmap))
@@ -56,8 +65,8 @@ for seed in range(first, first + runs):
             val = int(rng.integers(64, 128))
         events.setdefault(q, []).append((int(rng.integers(0, 2)), ctl, val))
         q += int(rng.integers(3, 45))
-    got = np.zeros((2, nb * 256), np.float32)
-    want = np.zeros((2, nb * 256))
+    got = np.zeros((2, nb * period), np.float32)
+    want = np.zeros((2, nb * period))
     q = 0
     while q < nb:
         for half, ctl, val in events.get(q, []):
@@ -65,14 +74,16 @@ for seed in range(first, first + runs):
             assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
         nxt = min([e for e in events if e > q] + [nb])
         n = 1 if rng.random() < 0.25 else int(min(rng.integers(2, 65), nxt - q))
-        s = slice(q * 256, (q + n) * 256)
-        for k in range(n):
-            ss = slice((q + k) * 256, (q + k + 1) * 256)
-            want[:, ss] = ref.process(x[0, ss], x[1, ss])
+        s = slice(q * period, (q + n) * period)
+        want[:, s] = ref.process(x[0, s], x[1, s], block=period)
+        if trace:
+            print(f"  call at {q}: {n} period(s), events {events.get(q, [])}, predelay {c.cc[0].value.predelay}/{c.cc[1].value.predelay} select {c.cc[0].value.select}/{c.cc[1].value.select}", flush=True)
         if n == 1:
             got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
         else:
             got[:, s] = c.process(x[0, s], x[1, s])
+        if trace:
+            c.sync()
         q += n
     st = c.drop_stats()
     c.close()
@@ -81,6 +92,6 @@ for seed in range(first, first + runs):
     err = float(np.sqrt(np.mean((got - want) ** 2)))
     flag = "" if err <= TOL else "   <-- FAIL"
     bad += err > TOL
-    print(f"seed {seed}: n_ref {n_ref}, IRs {lens}, {len(events)} event calls, rms {err:.3e} (signal {np.sqrt(np.mean(want ** 2)):.3e}, peak {np.abs(want).max():.2f}) {st}{flag}", flush=True)
+    print(f"seed {seed}: n_ref {n_ref}, period {period}, IRs {lens}, {len(events)} event calls, rms {err:.3e} (signal {np.sqrt(np.mean(want ** 2)):.3e}, peak {np.abs(want).max():.2f}) {st}{flag}", flush=True)
 print(f"{runs} runs, {bad} above {TOL}; batches by form of the cut terms: {tot}")
 sys.exit(1 if bad else 0)

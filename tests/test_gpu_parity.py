@@ -497,6 +497,46 @@ def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack, 
     c.close()
 
 
+@pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
+def test_q8_one_voice_with_irs_of_different_length(oracle_mod, gpu_lib, jack):
+    """A voice pairs half 0's IR with half 1's.  Here one is 60 partitions long and the other 40, at n_ref = 16384 with an
+    unaligned predelay of 4736 frames: the cut terms of the long one run over partitions 44 .. 59, which the short one does not
+    have - and its partition-major copy of the last partitions (k_h_tail: 48 of them) ends 11 partitions earlier.  Found by
+    scripts/fuzz_q8.py (seed 5002: a memory access fault - the sum reads both IRs' entries unconditionally and must take the
+    short one's from the zero-padded bank there)."""
+    from cuda_audio_amd.synth import make_input
+
+    n_ref, pd, taps = 16384, 4736, (10000, 15360)
+    nb = n_ref // 256 + 70
+    x = make_input(nb * 256, seed=29)
+    rng = np.random.default_rng(31)
+    irs = []
+    for L in taps:
+        h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (1.5 * L))[:, None]
+        irs.append((h * np.sqrt(0.003 / L)).astype(np.float32))
+    p0, p1 = dict(BASE, predelay=pd), dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=40)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    want = ref.process(x[0], x[1])
+    if jack:
+        got = np.concatenate([np.stack(c.onProcess(x[0, b * 256:(b + 1) * 256], x[1, b * 256:(b + 1) * 256])) for b in range(nb)], axis=1)
+    else:
+        got = np.concatenate([c.process(x[0, o * 256:min(o + 40, nb) * 256], x[1, o * 256:min(o + 40, nb) * 256]) for o in range(0, nb, 40)], axis=1)
+    c.close()
+    lin = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        lin.prepare(i, ir)
+    apply_params(lin, p0, p1, True)
+    assert rms(lin.process(x[0], x[1]) - want) > 5 * RMS_TOL  # (the cut terms matter)
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
 @pytest.mark.parametrize("sizes", [[120, 120, 60], [150, 1, 1, 148], [70, 230]], ids=["even", "periods_between", "short_then_long"])
 def test_q8_history_across_long_batches(oracle_mod, gpu_lib, sizes):
     """Q8 with batches longer than the look-back of the pass (one reference length + the largest predelay):
