@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(CORR_CHUNK) void k_corr_fix(CorrArgs A) {
 // Q8: the reference adds block t's N_ref-long contribution w_t[s] to its
 // accumulator at s + predelay and discards what falls past N_ref
 // (f_pointwiseAdd loops s < N, conv.cu:94-98).  For IRs and predelays with
-// taps + 255 + predelay > N_ref that cuts real signal: every output sample tau
+// taps + 255 + predelay > N_ref (calls of pm blocks: taps + 256 pm - 1 + predelay) that cuts real signal: every output sample tau
 // loses  sum_{t: 256 t <= tau - N_ref} w_t[tau - predelay - 256 t].  The lost
 // terms are recomputed here in the time domain (a 256-term dot product per
 // affected block, voice and path) and subtracted before the clamp; the host

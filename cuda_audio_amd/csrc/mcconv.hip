@@ -802,7 +802,10 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
         lmax = std::max<uint64_t>(lmax, std::max<uint64_t>(td.L0[v], td.L1[v]));
     }
     td.lmax = (int)lmax;
-    td.on = (e->cfg.compat && lmax + 255 + predelay > e->cfg.n_ref) ? 1 : 0;
+    // the reference transforms a whole call (pm blocks) at once: its contribution is taps + 256 pm - 1 frames long, and the cut applies to what
+    // passes n_ref frames after the START of the call - the last block of a call loses terms (pm - 1) blocks earlier than the first
+    // (scripts/fuzz_q8.py found the condition written for calls of one block: 1024-frame periods with taps + 1023 + predelay > n_ref >= taps + 255 + predelay)
+    td.on = (e->cfg.compat && lmax + (uint64_t)(MC_B * e->pm - 1) + predelay > e->cfg.n_ref) ? 1 : 0;
     td.xhist = e->d_xhist;
     td.xr = e->xr;
     td.gring = e->d_gring;
@@ -838,7 +841,7 @@ int prepare_drop_fft(mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_t predel
     for (int h = 0; h < 2; h++)
         for (int v = 0; v < MC_MAXV; v++)
             if (vir[h][v] >= 0) lmax = std::max<uint64_t>(lmax, e->irs[vir[h][v]].taps);
-    if (!(e->cfg.compat && lmax + 255 + predelay > e->cfg.n_ref) || e->half || !e->td_fft) return MC_OK;
+    if (!(e->cfg.compat && lmax + (uint64_t)(MC_B * e->pm - 1) + predelay > e->cfg.n_ref) || e->half || !e->td_fft) return MC_OK;
     for (int h = 0; h < 2; h++)
         for (int v = 0; v < MC_MAXV; v++)
             if (vir[h][v] >= 0) {

@@ -497,6 +497,49 @@ def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack, 
     c.close()
 
 
+@pytest.mark.parametrize("period,pd", [(1024, 256), (512, 700), (1024, 0)])
+@pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
+def test_q8_begins_earlier_for_longer_calls(oracle_mod, gpu_lib, period, pd, jack):
+    """The reference transforms a whole call at once: a call of pm blocks contributes taps + 256 pm - 1 frames, and what passes
+    n_ref frames after the START of the call is cut.  With taps = n_ref - 1024 and a 1024-frame period that happens from predelay 1
+    on - not from 770 on, as for calls of one block, which is where the engine switched its pass on until scripts/fuzz_q8.py ran
+    longer periods against the oracle (11 of 141 runs off by up to 5e-4).  (1024, 0): the boundary, nothing cut."""
+    from cuda_audio_amd.synth import make_input
+
+    n_ref, L, pm = 4096, 3072, period // 256
+    ncalls = (3 * n_ref // 256 // 2 + 24) // pm
+    x = make_input(ncalls * period, seed=41)
+    rng = np.random.default_rng(43)
+    irs = []
+    for k in range(2):
+        h = rng.standard_normal((L - 40 * k, 2)) * np.exp(-np.arange(L - 40 * k) / (2.0 * L))[:, None]
+        irs.append((h * np.sqrt(0.004 / L)).astype(np.float32))
+    p0, p1 = dict(BASE, predelay=pd), dict(BASE, select=1, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=6 * pm, period=period)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    want = ref.process(x[0], x[1], block=period)
+    step = 1 if jack else 5
+    parts = []
+    for k in range(0, ncalls, step):
+        s = slice(k * period, min(k + step, ncalls) * period)
+        parts.append(np.stack(c.onProcess(x[0, s], x[1, s])) if jack else c.process(x[0, s], x[1, s]))
+    got = np.concatenate(parts, axis=1)
+    c.close()
+    if pd:  # the cut terms are well above the bar: an engine that does not see the regime fails
+        lin = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            lin.prepare(i, ir)
+        apply_params(lin, p0, p1, True)
+        assert rms(lin.process(x[0], x[1], block=period) - want) > 5 * RMS_TOL
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
 @pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
 def test_q8_one_voice_with_irs_of_different_length(oracle_mod, gpu_lib, jack):
     """A voice pairs half 0's IR with half 1's.  Here one is 60 partitions long and the other 40, at n_ref = 16384 with an
