@@ -273,6 +273,7 @@ struct mc_engine {
     unsigned* hd_exited = nullptr;
     // how often a parked period was used / gave up on its own (host away > park_ms) / was told to give up: mc_debug_read item 6
     uint64_t n_park_hit = 0, n_park_timeout = 0, n_park_cancel = 0;
+    uint64_t n_mac_form[3] = {0, 0, 0};  // batches whose partition sums took the fused / split second-level transform / the resident MAC (mc_debug_read item 10)
     uint64_t n_drop_fft = 0, n_drop_ahead = 0, n_drop_tiles = 0;  // Q8 regime: batches by the form their cut terms took (mc_debug_read item 9)
 #ifdef MC_JACK_TRACE
     double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0;
@@ -1135,6 +1136,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                 mo->sc = 0;
                 mo->swept = pmax;
                 mo->lvl = -2;  // second-level transform, fused form
+                e->n_mac_form[0]++;
                 return MC_OK;
             }
             const int nseq = per_slot ? 4 * nact : 2;
@@ -1163,6 +1165,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
             mo->sc = 0;
             mo->swept = pmax;
             mo->lvl = -1;  // marks the second-level transform in the kernel statistics
+            e->n_mac_form[1]++;
             return MC_OK;
         }
     }
@@ -1210,6 +1213,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         mo->nsum = 1;
         mo->sc = 0;
         mo->lvl = lvl;
+        e->n_mac_form[2]++;
         mo->ffa_plane = (int64_t)plane;
         mo->main_n = T - S;
         // the last S blocks: streaming kernel, one set of chunk partials per voice
@@ -3328,6 +3332,11 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         const uint64_t g = which == 7 ? e->last_gen : e->ph.sample(cc);
         if (off + bytes > sizeof(uint64_t)) return fail(MC_ERR_ARG, "read beyond the generation word");
         std::memcpy(dst, reinterpret_cast<const char*>(&g) + off, bytes);
+        return MC_OK;
+    }
+    if (which == 10) {  // batches by the form their partition sums took {fused, split second-level transform, resident MAC}: no stream access
+        if (off + bytes > sizeof(e->n_mac_form)) return fail(MC_ERR_ARG, "read beyond the counters");
+        std::memcpy(dst, reinterpret_cast<const char*>(e->n_mac_form) + off, bytes);
         return MC_OK;
     }
     if (which == 9) {  // Q8 regime, batches: {cut terms summed by k_drop_fft for the whole batch, by the forward transforms (k_fwd<true>), in the time domain}: no stream access

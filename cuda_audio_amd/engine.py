@@ -267,6 +267,12 @@ class Convolution:
         check(self._L.mc_debug_read(self._h, 9, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
         return dict(drop_fft=int(a[0]), forward_transforms=int(a[1]), tiles=int(a[2]))
 
+    def mac_stats(self):
+        """Batch launches by the form their partition sums took (mc_debug_read item 10; host-side counters)."""
+        a = np.zeros(3, np.uint64)
+        check(self._L.mc_debug_read(self._h, 10, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return dict(fused=int(a[0]), split=int(a[1]), resident=int(a[2]))
+
     def param_generation(self, published=False):
         """Generation number of the parameter pair the last process call ran on (published=True: of the pair
         published last).  Every mc_set_params / mc_handle_cc publishes a new pair (csrc/params_handoff.h)."""

@@ -3,7 +3,9 @@
 Every run: random IR lengths up to n_ref - 1024 (several exactly there: the shipped shape), random controller traffic (select, predelay
 - often back to 1024 -, wet, speed, pans, level), and a random mix of batches (up to 64 blocks: longer than the reach of the cut terms, so the
 forward transforms sum them where the shape allows) and single periods.  usage: fuzz_q8.py [first_seed] [runs] [general]
-`general`: also periods of 512 / 1024 frames, up to 7 IRs of any length (more than the engine has voices: they merge), n_ref up to 16384, any predelay."""
+`general`: also periods of 512 / 1024 frames, up to 7 IRs of any length (more than the engine has voices: they merge), n_ref up to 16384, any predelay.
+`long`: `general` with batches of up to 1500 calls and the switch-over to the second-level transform lowered (MCCONV_FFT2_WORK=1, set here): the
+kernels of the headline (k_g2_mac; k_f2_* where gains differ per block and the IRs have >= 256 partitions: every fifth run is at n_ref = 131072)."""
 import ctypes as C
 import os
 import sys
@@ -19,19 +21,27 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-general = len(sys.argv) > 3 and sys.argv[3] == "general"
+long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
+general = long_ or (len(sys.argv) > 3 and sys.argv[3] == "general")
+if long_:
+    os.environ["MCCONV_FFT2_WORK"] = "1"
+BMAX = 1500 if long_ else 64  # calls per batch
 trace = os.environ.get("FUZZ_TRACE") == "1"  # every call printed before it runs and synchronised after it (fault triage)
 TOL = 1e-5
 cmap = (21, 22, 23, 24, 25, 26, 27, 28)
 arr = (C.c_uint8 * 8)(*cmap)
 bad = 0
-tot = dict(drop_fft=0, forward_transforms=0, tiles=0)
+tot = dict(drop_fft=0, forward_transforms=0, tiles=0, fused=0, split=0, resident=0)
 for seed in range(first, first + runs):
     rng = np.random.default_rng(seed)
     n_ref = int(rng.choice([4096, 8192, 16384] if general else [4096, 8192]))
+    if long_:
+        n_ref = 131072 if seed % 5 == 0 else int(rng.choice([8192, 16384]))
     period = int(rng.choice([256, 256, 512, 1024])) if general else 256
     pm = period // 256
     nb = (6 * n_ref // 256 + 200) // pm  # calls
+    if long_:
+        nb = (2600 if n_ref == 131072 else 4000) // pm
     nirs = int(rng.integers(2, 8 if general else 5))
     full = n_ref - 1024
     if general:
@@ -44,7 +54,7 @@ for seed in range(first, first + runs):
         irs.append((h * np.sqrt(0.003 / L)).astype(np.float32))
     x = make_input(nb * period, seed=100 + seed)
     ref = oracle_mod.RefCompat(n_ref, True)
-    c = Convolution("fuzz", n_ref, max_batch=64 * pm, stream_threshold=8, period=period)
+    c = Convolution("fuzz", n_ref, max_batch=BMAX * pm, stream_threshold=8, period=period)
     for i, ir in enumerate(irs):
         ref.prepare(i, ir)
         c.prepare(i, ir)
@@ -64,7 +74,7 @@ for seed in range(first, first + runs):
         if ctl == 28:
             val = int(rng.integers(64, 128))
         events.setdefault(q, []).append((int(rng.integers(0, 2)), ctl, val))
-        q += int(rng.integers(3, 45))
+        q += int(rng.integers(3, 45)) if not long_ else int(rng.integers(3, 900))
     got = np.zeros((2, nb * period), np.float32)
     want = np.zeros((2, nb * period))
     q = 0
@@ -73,7 +83,7 @@ for seed in range(first, first + runs):
             oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
             assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
         nxt = min([e for e in events if e > q] + [nb])
-        n = 1 if rng.random() < 0.25 else int(min(rng.integers(2, 65), nxt - q))
+        n = 1 if rng.random() < (0.1 if long_ else 0.25) else int(min(rng.integers(2, BMAX + 1), nxt - q))
         s = slice(q * period, (q + n) * period)
         want[:, s] = ref.process(x[0, s], x[1, s], block=period)
         if trace:
@@ -86,6 +96,7 @@ for seed in range(first, first + runs):
             c.sync()
         q += n
     st = c.drop_stats()
+    st.update(c.mac_stats())
     c.close()
     for k in tot:
         tot[k] += st[k]
@@ -93,5 +104,5 @@ for seed in range(first, first + runs):
     flag = "" if err <= TOL else "   <-- FAIL"
     bad += err > TOL
     print(f"seed {seed}: n_ref {n_ref}, period {period}, IRs {lens}, {len(events)} event calls, rms {err:.3e} (signal {np.sqrt(np.mean(want ** 2)):.3e}, peak {np.abs(want).max():.2f}) {st}{flag}", flush=True)
-print(f"{runs} runs, {bad} above {TOL}; batches by form of the cut terms: {tot}")
+print(f"{runs} runs, {bad} above {TOL}; batches by form of the cut terms and of the partition sums: {tot}")
 sys.exit(1 if bad else 0)
