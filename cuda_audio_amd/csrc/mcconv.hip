@@ -1230,6 +1230,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
         return MC_OK;
     }
     if (mo->resident) {
+        e->n_mac_form[2]++;
         // short batches: split the partition range so that the launch has ~2048 workgroups
         const int tiles = (T + 255) / 256;
         const int psplit = std::max(1, std::min(8, 8 / tiles));

@@ -54,7 +54,7 @@ for seed in range(first, first + runs):
         irs.append((h * np.sqrt(0.003 / L)).astype(np.float32))
     x = make_input(nb * period, seed=100 + seed)
     ref = oracle_mod.RefCompat(n_ref, True)
-    c = Convolution("fuzz", n_ref, max_batch=BMAX * pm, stream_threshold=8, period=period)
+    c = Convolution("fuzz", n_ref, max_batch=BMAX * pm, stream_threshold=8, period=period, pipeline=os.environ.get("FUZZ_PIPELINE") == "1")
     for i, ir in enumerate(irs):
         ref.prepare(i, ir)
         c.prepare(i, ir)
