@@ -1933,12 +1933,14 @@ __global__ __launch_bounds__(256) void k_drop_period(TailDrop td, float* __restr
 // The same period's terms in the frequency domain (the sum of k_drop_fft, one wave per block of the period: a period is too few
 // blocks for whole-line reads of the delay line to matter, the round trips do): per kappa one request of the gains, the four rows
 // of bins and their spectra together per partition, one inverse transform, one slice.  PM waves.
+// (body: every thread of the workgroup enters - the twiddles are loaded by all of them - and waves beyond the PM-th leave after the barrier)
 template <int PM>
-__global__ __launch_bounds__(64 * PM) void k_drop_period_fft(TailDrop td, float* __restrict__ drop, int64_t tabs0, int64_t pd, int64_t n_ref, int64_t blo) {
+__device__ __forceinline__ void drop_period_fft_body(const TailDrop& td, float* __restrict__ drop, int64_t tabs0, int64_t pd, int64_t n_ref, int64_t blo) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ __align__(16) float2 s_fft[PM][FFT_WAVE_LDS];
     load_twiddles(s_tw, td.g_tw);
     __syncthreads();
+    if (threadIdx.x >= 64 * PM) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float2* lds = s_fft[wave];
     float4* ybin = reinterpret_cast<float4*>(lds);  // [256] {Y_L, Y_R} per bin, before the transform reuses the memory
@@ -2042,6 +2044,10 @@ __global__ __launch_bounds__(64 * PM) void k_drop_period_fft(TailDrop td, float*
     }
     *reinterpret_cast<float4*>(drop + wave * MC_B + 4 * lane) = make_float4(dl[0], dl[1], dl[2], dl[3]);
     *reinterpret_cast<float4*>(drop + PM * MC_B + wave * MC_B + 4 * lane) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+}
+template <int PM>
+__global__ __launch_bounds__(64 * PM) void k_drop_period_fft(TailDrop td, float* __restrict__ drop, int64_t tabs0, int64_t pd, int64_t n_ref, int64_t blo) {
+    drop_period_fft_body<PM>(td, drop, tabs0, pd, n_ref, blo);
 }
 
 // ---------------------------------------------------------------------------
@@ -2742,11 +2748,17 @@ struct SweepArgs {
     float4 ugain;
     float2 inv;
     int nchunk;
+    float* drop_next;  // Q8 regime: != null: the launch's LAST workgroup sums the cut terms of the period after the tail's (block A.tabs0 + 1, the
+                       // tail's own TailDrop, predelay and epoch) into this buffer - like the sweep a speculation the next call checks: they
+                       // depend on blocks at least n_ref frames old, so nothing of them waits for a period (k_drop_period_fft as a launch
+                       // of its own cost the host a launch per period and, back to back, 5 us of stream time between two tails)
 };
 template <bool UNIFORM>
 __global__ __launch_bounds__(256) void k_jack(TailArgs A, SweepArgs S) {
     if (blockIdx.x == 0) {
         tail1_body(A);
+    } else if (S.drop_next && blockIdx.x == gridDim.x - 1) {
+        drop_period_fft_body<1>(A.td, S.drop_next, A.tabs0 + 1, A.predelay, A.n_ref, A.ret.b0);
     } else {
         const int w = (int)blockIdx.x - 1;
         mac_stream_body<UNIFORM, 256, false>(w & (MC_NB - 1), w >> 8, 0, S.H0, S.H1, S.pstride_ir, S.p_begin, S.p_end, S.chunk, S.fdl,

@@ -244,6 +244,15 @@ struct mc_engine {
     uint64_t batch_seq = 0;
     // speculative MAC of the next single block (partitions >= 1 do not depend on the next input)
     bool speculate = true, spec_valid = false;
+    // Q8 regime, JACK path: the cut terms a parked launch summed for the period after its own (SweepArgs.drop_next): valid for that block while
+    // predelay, epoch and the voices' IRs are what they were (everything else they depend on is at least n_ref frames old)
+    struct DropSpec {
+        bool valid = false;
+        uint64_t block = 0, predelay = 0, epoch_b0 = 0;
+        int vir[2][MC_MAXV];
+        const float* buf = nullptr;
+    } dspec;
+    bool carry_drop = true;  // MCCONV_CARRY_DROP=0: always a launch of its own (k_drop_period_fft) (measurement)
     uint64_t spec_block = 0;
     int spec_vir[2][MC_MAXV];
     int spec_nact = 0;
@@ -273,6 +282,7 @@ struct mc_engine {
     unsigned* hd_exited = nullptr;
     // how often a parked period was used / gave up on its own (host away > park_ms) / was told to give up: mc_debug_read item 6
     uint64_t n_park_hit = 0, n_park_timeout = 0, n_park_cancel = 0;
+    uint64_t n_drop_carried = 0;  // JACK path, Q8 regime: periods whose cut terms came with the launch before theirs (mc_debug_read item 9, fourth word)
     uint64_t n_mac_form[3] = {0, 0, 0};  // batches whose partition sums took the fused / split second-level transform / the resident MAC (mc_debug_read item 10)
     uint64_t n_drop_fft = 0, n_drop_ahead = 0, n_drop_tiles = 0;  // Q8 regime: batches by the form their cut terms took (mc_debug_read item 9)
 #ifdef MC_JACK_TRACE
@@ -451,7 +461,7 @@ int zero_state(mc_engine* e) {
         e->voice_ever[v] = false;
     }
     e->t_abs = e->t_front = 0;
-    e->spec_valid = false;
+    e->spec_valid = e->dspec.valid = false;
     e->uniform_valid[0] = e->uniform_valid[1] = false;
     e->pipe_head = e->pipe_count = 0;
     return MC_OK;
@@ -1378,7 +1388,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
     e->res_end = new_end;
     e->epoch_b0 = b0;
     e->cur_delay = new_delay;
-    e->spec_valid = false;
+    e->spec_valid = e->dspec.valid = false;
     return MC_OK;
 }
 
@@ -1477,7 +1487,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     const bool to_wet = (!lin && e->inv_to_wet) || lin_fused;
     st.ctx.wet_ready = to_wet;
     e->pipe[(e->pipe_head + e->pipe_count) % kPipe] = st.ctx;
-    e->spec_valid = false;
+    e->spec_valid = e->dspec.valid = false;
     BlockParams* d_ptab = st.d_ptab;
     float4* d_sums = st.d_sums;
     const int pstride = st.ctx.pstride;
@@ -1991,7 +2001,15 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
         A.exited = e->hd_exited;
         A.park_ticks = e->park_ticks;
-        A.drop = launch_drop_period(e, A.td, blk, st.ctx.predelay);  // (queued ahead of the tail this argument block is for)
+        {
+            const mc_engine::DropSpec& ds = e->dspec;
+            if (A.td.on && ds.valid && ds.block == blk && ds.predelay == st.ctx.predelay && ds.epoch_b0 == e->epoch_b0 &&
+                std::memcmp(ds.vir, st.ctx.vir, sizeof(ds.vir)) == 0) {
+                A.drop = ds.buf;  // (summed by the launch before this one)
+                e->n_drop_carried++;
+            } else
+                A.drop = launch_drop_period(e, A.td, blk, st.ctx.predelay);  // (queued ahead of the tail this argument block is for)
+        }
         A.in_gran = e->tio ? reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(e->d_bar) + 16384) : nullptr;
         A.out_gran = e->tio ? e->hd_gran : nullptr;
         return A;
@@ -2111,7 +2129,19 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                 S.inv = make_float2(1.f, 1.f);
                 S.nchunk = e->nchunk;
             }
-            const dim3 grid(1 + (pl_next.nsweep == 1 ? MC_NB * e->nchunk : 0));
+            // the cut terms of the period after the parked one ride along (its sweep does: same launch, one more workgroup)
+            const bool carry = e->carry_drop && A.td.on && A.td.fft && e->pm == 1;
+            S.drop_next = carry ? e->d_drop[blk2 & 1] : nullptr;
+            const dim3 grid(1 + (pl_next.nsweep == 1 ? MC_NB * e->nchunk : 0) + (carry ? 1 : 0));
+            e->dspec.valid = false;
+            if (carry) {
+                e->dspec.valid = true;
+                e->dspec.block = blk2;
+                e->dspec.predelay = st_next.ctx.predelay;
+                e->dspec.epoch_b0 = e->epoch_b0;
+                std::memcpy(e->dspec.vir, st_next.ctx.vir, sizeof(e->dspec.vir));
+                e->dspec.buf = S.drop_next;
+            }
             if (uni)
                 hipLaunchKernelGGL(k_jack<true>, grid, dim3(256), 0, e->stream, A, S);
             else
@@ -2838,6 +2868,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
     if (const char* fo = std::getenv("MCCONV_FUSE_DROP")) e->fuse_drop = std::atoi(fo) != 0;
     if (const char* fo = std::getenv("MCCONV_DROP_AHEAD")) e->drop_ahead = std::atoi(fo) != 0;
+    if (const char* fo = std::getenv("MCCONV_CARRY_DROP")) e->carry_drop = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
@@ -3043,7 +3074,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     ir.taps = n;
     ir.P = P;
     if ((int)idx + 1 > e->nirs) e->nirs = (int)idx + 1;
-    e->spec_valid = false;
+    e->spec_valid = e->dspec.valid = false;
     e->uniform_valid[0] = e->uniform_valid[1] = false;
     return MC_OK;
 }
@@ -3341,7 +3372,7 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         return MC_OK;
     }
     if (which == 9) {  // Q8 regime, batches: {cut terms summed by k_drop_fft for the whole batch, by the forward transforms (k_fwd<true>), in the time domain}: no stream access
-        const uint64_t c[3] = {e->n_drop_fft, e->n_drop_ahead, e->n_drop_tiles};
+        const uint64_t c[4] = {e->n_drop_fft, e->n_drop_ahead, e->n_drop_tiles, e->n_drop_carried};
         if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
         std::memcpy(dst, reinterpret_cast<const char*>(c) + off, bytes);
         return MC_OK;

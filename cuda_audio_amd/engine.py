@@ -263,9 +263,9 @@ class Convolution:
 
     def drop_stats(self):
         """Q8 regime: batches by the form their cut terms took (mc_debug_read item 9; host-side counters)."""
-        a = np.zeros(3, np.uint64)
+        a = np.zeros(4, np.uint64)
         check(self._L.mc_debug_read(self._h, 9, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
-        return dict(drop_fft=int(a[0]), forward_transforms=int(a[1]), tiles=int(a[2]))
+        return dict(drop_fft=int(a[0]), forward_transforms=int(a[1]), tiles=int(a[2]), carried_periods=int(a[3]))
 
     def mac_stats(self):
         """Batch launches by the form their partition sums took (mc_debug_read item 10; host-side counters)."""

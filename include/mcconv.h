@@ -224,7 +224,8 @@ uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
  * 4 = wet ring, 5 = Q1/Q2 prefix ring (double [rc][4]); host-side words, no stream access: 6 = JACK-path counters
  * {parked periods used, gave up on their own, told to give up} (3 x uint64), 7 / 8 = generation of the parameter
  * pair the last process call sampled / that was published last (uint64), 9 = batches in the Q8 regime by the form
- * their cut terms took {k_drop_fft, forward transforms, time-domain tiles} (3 x uint64), 10 = batch launches by the form
+ * their cut terms took {k_drop_fft, forward transforms, time-domain tiles} and JACK periods whose cut terms came with the
+ * launch before theirs (4 x uint64), 10 = batch launches by the form
  * of their partition sums {fused, split second-level transform, resident MAC} (3 x uint64).  dims[0..3] receive
  * {pstride, ring, max_batch, wet ring length} when non-null. */
 int mc_debug_read(mc_engine *e, int which, uint64_t idx, void *dst, uint64_t offset_bytes, uint64_t bytes,

@@ -4,6 +4,8 @@ Every run: random IR lengths up to n_ref - 1024 (several exactly there: the ship
 - often back to 1024 -, wet, speed, pans, level), and a random mix of batches (up to 64 blocks: longer than the reach of the cut terms, so the
 forward transforms sum them where the shape allows) and single periods.  usage: fuzz_q8.py [first_seed] [runs] [general]
 `general`: also periods of 512 / 1024 frames, up to 7 IRs of any length (more than the engine has voices: they merge), n_ref up to 16384, any predelay.
+`jack`: single 256-frame periods only, 1200 of them, controller events 40-250 calls apart: the parked path (and, in the Q8 regime, the cut terms
+carried by the launch before) under parameter changes.
 `long`: `general` with batches of up to 1500 calls and the switch-over to the second-level transform lowered (MCCONV_FFT2_WORK=1, set here): the
 kernels of the headline (k_g2_mac; k_f2_* where gains differ per block and the IRs have >= 256 partitions: every fifth run is at n_ref = 131072)."""
 import ctypes as C
@@ -22,6 +24,7 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
+jack = len(sys.argv) > 3 and sys.argv[3] == "jack"  # single periods only, events far enough apart that the periods in between are parked one call ahead
 general = long_ or (len(sys.argv) > 3 and sys.argv[3] == "general")
 if long_:
     os.environ["MCCONV_FFT2_WORK"] = "1"
@@ -31,7 +34,7 @@ TOL = 1e-5
 cmap = (21, 22, 23, 24, 25, 26, 27, 28)
 arr = (C.c_uint8 * 8)(*cmap)
 bad = 0
-tot = dict(drop_fft=0, forward_transforms=0, tiles=0, fused=0, split=0, resident=0)
+tot = dict(drop_fft=0, forward_transforms=0, tiles=0, carried_periods=0, fused=0, split=0, resident=0)
 for seed in range(first, first + runs):
     rng = np.random.default_rng(seed)
     n_ref = int(rng.choice([4096, 8192, 16384] if general else [4096, 8192]))
@@ -40,6 +43,8 @@ for seed in range(first, first + runs):
     period = int(rng.choice([256, 256, 512, 1024])) if general else 256
     pm = period // 256
     nb = (6 * n_ref // 256 + 200) // pm  # calls
+    if jack:
+        n_ref, nb = 4096, 1200
     if long_:
         nb = (2600 if n_ref == 131072 else 4000) // pm
     nirs = int(rng.integers(2, 8 if general else 5))
@@ -75,7 +80,7 @@ for seed in range(first, first + runs):
         if ctl == 28:
             val = int(rng.integers(64, 128))
         events.setdefault(q, []).append((int(rng.integers(0, 2)), ctl, val))
-        q += int(rng.integers(3, 45)) if not long_ else int(rng.integers(3, 900))
+        q += int(rng.integers(3, 45)) if not (long_ or jack) else int(rng.integers(3, 900) if long_ else rng.integers(40, 250))
     got = np.zeros((2, nb * period), np.float32)
     want = np.zeros((2, nb * period))
     q = 0
@@ -84,7 +89,7 @@ for seed in range(first, first + runs):
             oracle_mod.handle_cc(ref.cc(half), cmap, ctl, val, ref.num_irs())
             assert c._L.mc_handle_cc(c._h, half, arr, ctl, val) == 0
         nxt = min([e for e in events if e > q] + [nb])
-        n = 1 if rng.random() < (0.1 if long_ else 0.25) else int(min(rng.integers(2, BMAX + 1), nxt - q))
+        n = 1 if jack or rng.random() < (0.1 if long_ else 0.25) else int(min(rng.integers(2, BMAX + 1), nxt - q))
         s = slice(q * period, (q + n) * period)
         want[:, s] = ref.process(x[0, s], x[1, s], block=period)
         if trace:

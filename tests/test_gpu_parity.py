@@ -4,6 +4,8 @@ Sizes are chosen so the oracle finishes in seconds; BASELINE-size cases use the
 partitioned oracle form (proven equal to the single-FFT restatement to 1e-16 in
 tests/test_oracle.py) and size-independent properties.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -495,6 +497,43 @@ def test_q8_tail_drop_is_reproduced(oracle_mod, gpu_lib, n_ref, taps, pd, jack, 
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
     c.close()
+
+
+def test_q8_parked_periods_carry_the_next_periods_cut_terms(oracle_mod, gpu_lib):
+    """JACK path in the Q8 regime once the parameters are steady (the cold-start ramp takes ~160 calls): every period is
+    parked one call ahead, and the launch that carries it also sums the cut terms of the period after it (k_jack's last
+    workgroup) - no launch of their own.  A controller change in between (predelay 1024 -> 1088 -> 1024: a new epoch, the
+    carried terms are stale) must fall back to k_drop_period_fft; the samples are the oracle's throughout."""
+    from cuda_audio_amd.synth import make_input
+
+    n_ref, L, nb = 4096, 3072, 300
+    x = make_input(nb * 256, seed=53)
+    rng = np.random.default_rng(59)
+    h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (2.0 * L))[:, None]
+    ir = (h * np.sqrt(0.004 / L)).astype(np.float32)
+    p0, p1 = dict(BASE, predelay=1024), dict(BASE, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=8)
+    ref.prepare(0, ir)
+    c.prepare(0, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    events = {230: 1088, 262: 1024}
+    for b in range(nb):
+        if b in events:
+            ref.set(0, predelay=events[b])
+            c.cc[0].value.predelay = events[b]
+        s = slice(b * 256, (b + 1) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+    stats, parks = c.drop_stats(), c.park_stats()
+    c.close()
+    err = rms(got - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e}) {stats} {parks}"
+    if not any(os.environ.get(k) for k in ("MCCONV_NO_PARK", "MCCONV_NO_SPECULATE", "MCCONV_NO_SPIN", "MCCONV_TD_FFT", "MCCONV_CARRY_DROP")):
+        assert parks["used"] > 40 and stats["carried_periods"] > 40, (stats, parks)
 
 
 @pytest.mark.parametrize("period,pd", [(1024, 256), (512, 700), (1024, 0)])
