@@ -1160,6 +1160,9 @@ def main():
                     ns[k] = rp[k]
             if "sharded_check" in rp:
                 ns["sharded_check"] = rp["sharded_check"]
+                if world == 1 and shard_world > 1:  # (one GPU acting as rank 0 of an emulated world: a timing run)
+                    ns["sharded_check"]["note"] = (f"emulated world of {shard_world} on one GPU: the sum holds this rank's partitions only, so the difference "
+                                                   "to the unsharded engine IS the other ranks' share - not a parity figure")
             if by_blocks:
                 line["north_star_layout"] = ns
             else:
