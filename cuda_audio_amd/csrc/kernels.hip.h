@@ -2778,7 +2778,9 @@ __global__ __launch_bounds__(256) void k_jack(TailArgs A, SweepArgs S) {
 // The blocks of a call share one parameter entry (the reference advances its
 // cross-fade once per call) and the Q1/Q2/Q8 windows start at the call.
 // ---------------------------------------------------------------------------
-template <int PM>
+// SELF_DROP (a parked launch in the Q8 regime): the workgroup sums the period's own cut terms first, while the period has not arrived
+// (they depend on blocks at least n_ref frames old) - no launch of their own ahead of this one.
+template <int PM, bool SELF_DROP>
 #ifdef TAILP_VGPR_CAP  // (measurement build: DESIGN section 4, JACK path, item 3)
 __attribute__((amdgpu_num_vgpr(TAILP_VGPR_CAP)))
 #endif
@@ -2795,6 +2797,10 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
                                                const unsigned long long* in_gran, unsigned long long* out_gran) {
     // bell != null: launched one call ahead, parks on its doorbell like the single-block tail (tail1_body)
     static_assert(PM == 2 || PM == 4, "one wave per block of the call");
+    if (SELF_DROP) {
+        drop_period_fft_body<PM>(td, const_cast<float*>(drop), tabs0, predelay, n_ref, ret.b0);
+        __syncthreads();  // (the workgroup's own stores, read back below)
+    }
     __shared__ float2 s_tw[FFT_N];
     __shared__ float2 s_fft[PM][FFT_WAVE_LDS];
     __shared__ float4 s_xy[PM][MC_NB];  // spectra {X1, X2} of the new blocks, then {Y_L, Y_R}

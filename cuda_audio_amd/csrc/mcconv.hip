@@ -2470,9 +2470,14 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         const unsigned long long* bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
         (void)prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
         const TailDrop tdp = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
-        const float* drop = launch_drop_period(e, tdp, blk, st.ctx.predelay);
+        // Q8 regime: a parked tail sums its own cut terms while it waits for the period; one launched on arrival gets them from a launch ahead of it
+        const bool self_drop = parked && tdp.on && tdp.fft && e->carry_drop;
+        const float* drop = self_drop ? e->d_drop[(blk / (uint64_t)e->pm) & 1] : launch_drop_period(e, tdp, blk, st.ctx.predelay);
+        if (self_drop) e->n_drop_carried++;
 #define MC_LAUNCH_TAILP(PM)                                                                                                  \
-    hipLaunchKernelGGL(k_tailp<PM>, dim3(1), dim3(256), 0, e->stream, pin1, pin2, pl.vset, e->Pstride, e->d_fdl, e->d_slotgain, \
+    if (self_drop) MC_LAUNCH_TAILP_(PM, true); else MC_LAUNCH_TAILP_(PM, false)
+#define MC_LAUNCH_TAILP_(PM, SD)                                                                                                  \
+    hipLaunchKernelGGL((k_tailp<PM, SD>), dim3(1), dim3(256), 0, e->stream, pin1, pin2, pl.vset, e->Pstride, e->d_fdl, e->d_slotgain, \
                        e->ring, slot0, e->d_part, pl.nsum, st.d_ptab, e->d_seg, e->sr, e->d_wet, e->wr, e->d_cring, e->rc,    \
                        st.ctx.vs, 1.0 / (double)e->cfg.n_ref, (int)e->cfg.compat, (int64_t)blk, (int64_t)st.ctx.predelay,     \
                        (int64_t)e->cfg.n_ref, e->hd_io + 2 * cap, e->hd_io + 3 * cap, e->d_tw,                                \
@@ -2480,11 +2485,13 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
                        e->hd_exited, e->park_ticks, drop,                            \
                        tio_p ? reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(e->d_bar) + 16384) : nullptr, \
                        tio_p ? e->hd_gran : nullptr)
-        if (pm == 2)
+        if (pm == 2) {
             MC_LAUNCH_TAILP(2);
-        else
+        } else {
             MC_LAUNCH_TAILP(4);
+        }
 #undef MC_LAUNCH_TAILP
+#undef MC_LAUNCH_TAILP_
     };
     auto same_cc = [](const mc_cc_value& a, const mc_cc_value& b) {  // (field by field: the struct has padding)
         return a.select == b.select && a.predelay == b.predelay && a.speed == b.speed && a.vsteps == b.vsteps && a.dry == b.dry &&

@@ -24,7 +24,7 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
-jack = len(sys.argv) > 3 and sys.argv[3] == "jack"  # single periods only, events far enough apart that the periods in between are parked one call ahead
+jack = len(sys.argv) > 3 and sys.argv[3].startswith("jack")  # (jack512 / jack1024: periods of that many frames)  # single periods only, events far enough apart that the periods in between are parked one call ahead
 general = long_ or (len(sys.argv) > 3 and sys.argv[3] == "general")
 if long_:
     os.environ["MCCONV_FFT2_WORK"] = "1"
@@ -45,6 +45,8 @@ for seed in range(first, first + runs):
     nb = (6 * n_ref // 256 + 200) // pm  # calls
     if jack:
         n_ref, nb = 4096, 1200
+        period = int(sys.argv[3][4:] or 256)
+        pm = period // 256
     if long_:
         nb = (2600 if n_ref == 131072 else 4000) // pm
     nirs = int(rng.integers(2, 8 if general else 5))

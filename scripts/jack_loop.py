@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The JACK path in a loop (one 256-frame period per mc_process call, config 3) - the program scripts/profile_jack.sh
+"""The JACK path in a loop (one 256-frame period per mc_process call, config 3; JACK_SHIPPED=1: the reference's shipped operating point) - the program scripts/profile_jack.sh
 runs under rocprofv3.  Prints microseconds per call."""
 import ctypes as C
 import os
@@ -15,11 +15,17 @@ from cuda_audio_amd.synth import make_input, make_ir  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 gap_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0  # idle time between calls (a JACK period is 5805 us)
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 256         # frames per period (256, 512, 1024)
-c = Convolution("jack", 524288, max_batch=8, device=0, period=F)
-c.prepare(0, make_ir(441000, seed=5678))
-c.prepare(1, make_ir(441000, seed=5680))
-for h in (0, 1):
-    c.cc[h].value.update(select=h, vsteps=0)
+if os.environ.get("JACK_SHIPPED") == "1":  # the reference's shipped operating point (settings.txt:19,38-45): the Q8 regime
+    c = Convolution("jack", 131072, max_batch=8, device=0, period=F)
+    c.prepare(0, make_ir(131072 - 1024, seed=5678))
+    for h in (0, 1):
+        c.cc[h].value.update(select=0, predelay=1024, vsteps=0)
+else:
+    c = Convolution("jack", 524288, max_batch=8, device=0, period=F)
+    c.prepare(0, make_ir(441000, seed=5678))
+    c.prepare(1, make_ir(441000, seed=5680))
+    for h in (0, 1):
+        c.cc[h].value.update(select=h, vsteps=0)
 x = make_input(F)
 fp = C.POINTER(C.c_float)
 bufs = [np.ascontiguousarray(x[0]), np.ascontiguousarray(x[1]), np.zeros(F, np.float32), np.zeros(F, np.float32)]
