@@ -3991,6 +3991,20 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_g2_mac(const float4* __restr
         return;
     }
     const int nch = nitems >> 8;
+#ifndef G2_PRIO
+#define G2_PRIO 3
+#endif
+#if G2_PRIO  // The two workgroups of a CU sit in wave slots {0, 1} and {2, 3} of every SIMD (scripts/probes/cuid_probe.hip).  The upper pair gets issue
+             // priority: whenever both want to issue, one of them goes first every time instead of taking turns - 367-372 -> 353-354 us per headline
+             // launch, -2 ... -4 % for configs 2, 5 and the shipped point, same bits (profiles/r3_g2_ablation.md, section 7; -DG2_PRIO=0: without).
+             // Only for launches of at least four rounds of workgroups: in a short one the disadvantaged workgroup of the last round IS the
+             // launch's tail (8192 blocks: 47 -> 55 us, 32320: 105 -> 113 with it)
+    if (nitems >= 2048) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid & 0xfu) >= 2u) __builtin_amdgcn_s_setprio(G2_PRIO);
+    }
+#endif
     g2_tables(t_lo, t_hi);
     __syncthreads();  // the first forward pass runs on registers: nothing else orders its twiddle reads after the tables
 #if G2_STAMPS  // diagnostic build only: where a workgroup's time goes (s_memtime ticks = shader cycles)
