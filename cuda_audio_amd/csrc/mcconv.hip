@@ -815,7 +815,7 @@ TailDrop make_taildrop(const mc_engine* e, const int (&vir)[2][MC_MAXV], uint64_
     td.lmax = (int)lmax;
     // the reference transforms a whole call (pm blocks) at once: its contribution is taps + 256 pm - 1 frames long, and the cut applies to what
     // passes n_ref frames after the START of the call - the last block of a call loses terms (pm - 1) blocks earlier than the first
-    // (scripts/fuzz_q8.py found the condition written for calls of one block: 1024-frame periods with taps + 1023 + predelay > n_ref >= taps + 255 + predelay)
+    // (tests/fuzz/fuzz_q8.py found the condition written for calls of one block: 1024-frame periods with taps + 1023 + predelay > n_ref >= taps + 255 + predelay)
     td.on = (e->cfg.compat && lmax + (uint64_t)(MC_B * e->pm - 1) + predelay > e->cfg.n_ref) ? 1 : 0;
     td.xhist = e->d_xhist;
     td.xr = e->xr;

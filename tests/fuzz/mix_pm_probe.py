@@ -1,6 +1,8 @@
+"""Periods of 256 / 512 / 1024 frames, batches and single periods mixed, per-call error against oracle.RefCompat: the probe that located the
+Q8 regime's late start for longer calls (round 3)."""
 import os, sys
 import numpy as np
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"tests"))
 import oracle as oracle_mod
 from cuda_audio_amd.engine import Convolution

@@ -541,7 +541,7 @@ def test_q8_parked_periods_carry_the_next_periods_cut_terms(oracle_mod, gpu_lib)
 def test_q8_begins_earlier_for_longer_calls(oracle_mod, gpu_lib, period, pd, jack):
     """The reference transforms a whole call at once: a call of pm blocks contributes taps + 256 pm - 1 frames, and what passes
     n_ref frames after the START of the call is cut.  With taps = n_ref - 1024 and a 1024-frame period that happens from predelay 1
-    on - not from 770 on, as for calls of one block, which is where the engine switched its pass on until scripts/fuzz_q8.py ran
+    on - not from 770 on, as for calls of one block, which is where the engine switched its pass on until tests/fuzz/fuzz_q8.py ran
     longer periods against the oracle (11 of 141 runs off by up to 5e-4).  (1024, 0): the boundary, nothing cut."""
     from cuda_audio_amd.synth import make_input
 
@@ -584,7 +584,7 @@ def test_q8_one_voice_with_irs_of_different_length(oracle_mod, gpu_lib, jack):
     """A voice pairs half 0's IR with half 1's.  Here one is 60 partitions long and the other 40, at n_ref = 16384 with an
     unaligned predelay of 4736 frames: the cut terms of the long one run over partitions 44 .. 59, which the short one does not
     have - and its partition-major copy of the last partitions (k_h_tail: 48 of them) ends 11 partitions earlier.  Found by
-    scripts/fuzz_q8.py (seed 5002: a memory access fault - the sum reads both IRs' entries unconditionally and must take the
+    tests/fuzz/fuzz_q8.py (seed 5002: a memory access fault - the sum reads both IRs' entries unconditionally and must take the
     short one's from the zero-padded bank there)."""
     from cuda_audio_amd.synth import make_input
 
