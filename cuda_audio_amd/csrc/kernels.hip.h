@@ -1216,6 +1216,7 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
 // (5 us each as kernels: launch and drain latency, not work).
 struct CorrArgs {
     const float4* sums;
+    const float4* parts;  // != null: sums[t] = the sum of the sixteen partial sums parts[16 t ..] (the column pass of ossave.hip.h)
     const BlockParams* ptab;
     int pstride, T;
     VoiceSums vs;
@@ -1258,8 +1259,22 @@ __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], con
     }
     const int t = (cb < A.nrun0 ? A.run0 + cb * CORR_CHUNK : A.run1 + (cb - A.nrun0) * CORR_CHUNK) + tid;
     double d[4] = {0, 0, 0, 0};
-    if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0))
-        corr_terms(A.sums[t], A.ptab[(int64_t)t * A.pstride], A.vs, A.inv_n, d);
+    if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0)) {
+        float4 sa;
+        if (A.parts) {  // sixteenths in frame order, summed pairwise
+            const float4* q = A.parts + (size_t)t * 16;
+            float4 h[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) h[i] = q[i];
+#pragma unroll
+            for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w; i++) h[i] = make_float4(h[i].x + h[i + w].x, h[i].y + h[i + w].y, h[i].z + h[i + w].z, h[i].w + h[i + w].w);
+            sa = h[0];
+        } else
+            sa = A.sums[t];
+        corr_terms(sa, A.ptab[(int64_t)t * A.pstride], A.vs, A.inv_n, d);
+    }
     if (!A.chain && A.nchunks == 1 && tid == 0 && A.tabs0 > 0) {
         const double* p = A.cring + (size_t)((A.tabs0 - 1) & (A.rc - 1)) * 4;
         for (int c = 0; c < 4; c++) d[c] += p[c];

@@ -23,6 +23,7 @@
 #include "../../include/mcconv.h"
 #include "params_handoff.h"
 #include "kernels.hip.h"
+#include "ossave.hip.h"
 #include "singlefft.hip.h"
 
 namespace {
@@ -314,6 +315,31 @@ struct mc_engine {
     bool g2_duo = false;
     int g2_duo_minch = 3, g2_duo_grid = 256;
     bool g2_wide = false;    // MCCONV_G2_WIDE=1: the one-workgroup-per-CU form of the kernel (1024 threads, both sequences in LDS)
+    // Long settled batches as overlap-save segments of 512 x 8192 frames (ossave.hip.h): whole batches on one fp32 engine whose
+    // window carries one set of gains, outside the Q8 regime.  Buffers and the spectra of the sounding (IR set, gains) are
+    // made by the first batch that takes the form.
+    bool os_on = true;          // MCCONV_OS=0: such batches through the second-level transform as before (measurement)
+    int os_min_blocks = 12288;  // shortest batch that takes the form (a segment costs the same however little of it is used)
+    float4* d_os_T = nullptr;   // [segments][256 row pairs][8192] {row k1, row 512 - k1} between the passes
+    size_t os_T_segs = 0;
+    float4* d_os_part = nullptr;  // [Tmax][16] sixteenths of the blocks' sums {S1, S2, A1, A2}
+    float4 *d_os_SP = nullptr, *d_os_SP0 = nullptr;  // spectra A, B of the cached key, in the row pass's order
+    float* d_os_planes = nullptr;  // gain-weighted taps, four planes of os_planes_n floats
+    size_t os_planes_n = 0;
+    struct OsKey {
+        bool valid = false;
+        int n = 0;
+        int ir0[MC_MAXV], ir1[MC_MAXV];
+        float g[MC_MAXV][4];
+        uint64_t gen = 0;
+    } os_key;
+    uint64_t ir_gen = 0;                  // counts changes of any IR's taps (load, reload, merge)
+    uint64_t n_os[2] = {0, 0};            // batches that took the form, spectra builds (mc_debug_read item 11)
+    // the small launches of such a batch - prefix sums, the tail's delay-line slots, the last block's segment - run on a side
+    // stream beside the three passes (MCCONV_OS_SIDE=0: in line, measurement)
+    bool os_side = true;
+    hipStream_t os_stream = nullptr;
+    hipEvent_t os_ev[3] = {nullptr, nullptr, nullptr};
     int ffa_levels = 3;   // resident MAC in fast-FIR form (up to this many nested levels) when batch and IR are long enough
     bool sliced = false;  // block-sliced calls keep no wet / segment history outside their slices
     bool inv_to_wet = true;  // whole-batch path: k_inv_wet + ring-reading k_post (MCCONV_INV_WET=0: k_inv + segment ring)
@@ -573,6 +599,7 @@ int consolidate_voices(mc_engine* e, int i) {
     hipLaunchKernelGGL(k_mix, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<float*>(M.d_h), (size_t)taps * 2, sh);
     HIP_TRY(hipGetLastError());
     invalidate_derived(M);
+    e->ir_gen++;
     std::memcpy(M.sums, sums, sizeof(sums));
     M.taps = taps;
     M.P = P;
@@ -1406,6 +1433,224 @@ void corr_chunks(CorrArgs* ca, int T, int need_a0, int need_a1, int need_b0) {
     ca->nchunks = ca->nrun0 + nrun1;
 }
 
+// ---------------------------------------------------------------------------
+// Long settled batches as overlap-save segments (ossave.hip.h).
+// ---------------------------------------------------------------------------
+// Can this whole batch take the form?  One fp32 engine finishing its own output, one set of gains over the batch and the
+// window before it, no Q8 pass, no retired predelay epoch ringing out, the segments' history inside the live epoch.
+bool os_applies(const mc_engine* e, const Staged& st, int T, const float* d_in1, const float* d_in2, const float* d_outL,
+                const float* d_outR, int* ovl_blocks) {
+    if (!e->os_on || e->half || e->pipelined || !e->fuse_out || !e->inv_to_wet || e->sliced) return false;
+    if (e->cfg.part_begin || e->cfg.part_end || !d_outL || !d_outR || T < e->os_min_blocks || st.ctx.pstride != 0 || st.nact <= 0) return false;
+    if ((reinterpret_cast<uintptr_t>(d_in1) | reinterpret_cast<uintptr_t>(d_in2) | reinterpret_cast<uintptr_t>(d_outL) | reinterpret_cast<uintptr_t>(d_outR)) & 15) return false;
+    int pmax = 0;
+    for (int a = 0; a < st.nact; a++) {
+        if (!st.act[a].uniform) return false;
+        pmax = std::max(pmax, st.act[a].p_end);
+    }
+    if (pmax <= 0 || (int64_t)pmax * MC_B > OS_N / 2) return false;  // (a segment at least half new frames)
+    if (e->res_end > e->t_front * MC_B) return false;
+    if (e->epoch_b0 != 0 && e->epoch_b0 + (uint64_t)pmax > e->t_front) return false;
+    if (make_taildrop(e, st.ctx.vir, st.ctx.predelay).on) return false;
+    *ovl_blocks = pmax;
+    return true;
+}
+
+// buffers for nseg segments and the spectra of the batch's (IR set, gains)
+int ensure_os(mc_engine* e, const Staged& st, int nseg) {
+    const size_t seg_el = (size_t)OS_ITEMS * OS_N2;
+    const size_t want = (size_t)std::max(nseg, 2);  // (the spectra are built in two segments' worth of it)
+    if (e->os_T_segs < want) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_os_T) (void)hipFree(e->d_os_T);
+        e->d_os_T = nullptr;
+        e->os_T_segs = 0;
+        HIP_TRY(hipMalloc(&e->d_os_T, sizeof(float4) * seg_el * want));
+        e->os_T_segs = want;
+    }
+    if (!e->d_os_part) HIP_TRY(hipMalloc(&e->d_os_part, sizeof(float4) * 16 * (size_t)e->Tmax));
+    if (e->os_side && !e->os_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->os_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreateWithFlags(&e->os_ev[i], hipEventDisableTiming));
+    }
+    if (!e->d_os_SP) HIP_TRY(hipMalloc(&e->d_os_SP, sizeof(float4) * seg_el * 2));
+    if (!e->d_os_SP0) HIP_TRY(hipMalloc(&e->d_os_SP0, sizeof(float4) * 2 * OS_N2));
+    mc_engine::OsKey key;
+    OsMix mix;
+    std::memset(&mix, 0, sizeof(mix));
+    key.valid = true;
+    key.n = st.nact;
+    key.gen = e->ir_gen;
+    int64_t lmax = 4;
+    for (int a = 0; a < MC_MAXV; a++) {
+        key.ir0[a] = key.ir1[a] = -1;
+        key.g[a][0] = key.g[a][1] = key.g[a][2] = key.g[a][3] = 0.f;
+        if (a >= st.nact) continue;
+        const ActiveVoice& av = st.act[a];
+        key.ir0[a] = (int)(av.ir0 - e->irs);
+        key.ir1[a] = (int)(av.ir1 - e->irs);
+        key.g[a][0] = av.ugain.x, key.g[a][1] = av.ugain.y, key.g[a][2] = av.ugain.z, key.g[a][3] = av.ugain.w;
+        mix.h0[a] = av.ir0->d_h;
+        mix.h1[a] = av.ir1->d_h;
+        mix.L0[a] = (int)av.ir0->taps;
+        mix.L1[a] = (int)av.ir1->taps;
+        mix.g[a] = av.ugain;
+        lmax = std::max<int64_t>(lmax, std::max<int64_t>(mix.L0[a], mix.L1[a]));
+    }
+    mix.n = st.nact;
+    const mc_engine::OsKey& k0 = e->os_key;
+    if (k0.valid && k0.n == key.n && k0.gen == key.gen && !std::memcmp(k0.ir0, key.ir0, sizeof(key.ir0)) &&
+        !std::memcmp(k0.ir1, key.ir1, sizeof(key.ir1)) && !std::memcmp(k0.g, key.g, sizeof(key.g)))
+        return MC_OK;
+    const int64_t np = (lmax + 3) & ~(int64_t)3;
+    if (e->os_planes_n < (size_t)np) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_os_planes) (void)hipFree(e->d_os_planes);
+        e->d_os_planes = nullptr;
+        e->os_planes_n = 0;
+        HIP_TRY(hipMalloc(&e->d_os_planes, sizeof(float) * 4 * (size_t)np));
+        e->os_planes_n = (size_t)np;
+    }
+    e->os_key.valid = false;
+    hipLaunchKernelGGL(k_os_ir_mix, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, e->stream, mix, e->d_os_planes, np);
+    OsGeo G;
+    G.hop = OS_N;
+    G.ovl = 0;
+    G.n_in = np;
+    G.tau0 = 0;
+    G.seg0 = 0;
+    for (int i = 0; i < 2; i++) {
+        float4* buf = e->d_os_T + seg_el * i;
+        hipLaunchKernelGGL(k_os_cols, dim3(OS_TPS), dim3(OS_THREADS), 0, e->stream, e->d_os_planes + (size_t)np * 2 * i,
+                           e->d_os_planes + (size_t)np * (2 * i + 1), (const float*)nullptr, 0, G, buf, (float4*)nullptr, e->d_tw);
+        hipLaunchKernelGGL(k_os_rows_fwd, dim3(OS_ITEMS), dim3(G2_THREADS), 0, e->stream, buf);
+    }
+    hipLaunchKernelGGL(k_os_ir_combine, dim3(OS_ITEMS), dim3(512), 0, e->stream, e->d_os_T, e->d_os_T + seg_el, e->d_os_SP, e->d_os_SP0,
+                       0.5f / (float)OS_N);
+    HIP_TRY(hipGetLastError());
+    e->os_key = key;
+    e->n_os[1]++;
+    return MC_OK;
+}
+
+// The whole batch (T blocks from e->t_front, already staged in `st`) through the overlap-save passes.  Leaves the engine as
+// the partitioned passes would: the last blocks' delay-line slots, slot gains and histories (k_fwd over the batch's tail), the
+// Q1/Q2 prefix ring, the wet ring where later calls reach, and the last block's segment (its second half opens the next call).
+int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const float* d_in1, const float* d_in2, float* d_outL, float* d_outR,
+           int T, int ovl_blocks, int slot0) {
+    const int64_t ovl = (int64_t)ovl_blocks * MC_B, hop = (int64_t)OS_N - ovl;
+    const int hop_blocks = (int)(hop / MC_B);
+    const int nseg = (T + hop_blocks - 1) / hop_blocks;
+    int rc = ensure_os(e, st, nseg);
+    if (rc) return rc;
+    const BlockParams* d_ptab = st.d_ptab;
+    const hipStream_t main = e->stream, side = e->os_side ? e->os_stream : e->stream;
+    if (side != main) {  // the side stream starts where the engine's stream stands
+        HIP_TRY(hipEventRecord(e->os_ev[0], main));
+        HIP_TRY(hipStreamWaitEvent(side, e->os_ev[0], 0));
+    }
+    // state for later calls: delay line, slot gains, input / gain histories of the last blocks (what any later window,
+    // Q8 pass or re-render of a predelay epoch can reach), and the last block's segment as the partitioned passes leave it
+    // (its partition sums from the delay line, one inverse transform: its second half opens the next call)
+    {
+        const int reach = std::max(round_up(e->Pcap, 16) + 64, (int)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B) + 8);
+        const int from = std::max(0, T - reach) & ~(FWD_TILE - 1);
+        const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
+        DropAhead da;
+        std::memset(&da, 0, sizeof(da));
+        hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
+                           e->d_fdl, e->ring, slot0, d_ptab, 0, (float4*)nullptr, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
+                           e->rc, (int64_t)e->t_front, 0, 0, from, hist_from, from, da);
+        MacOut mo;
+        const uint64_t b = e->t_front + (uint64_t)T - 1;
+        e->stream = side;  // (the MAC and inverse-transform launchers use the engine's stream)
+        rc = launch_mac_batch(e, st.act, st.nact, false, 1, (int)(b & (uint64_t)(e->ring - 1)), &mo);
+        if (!rc) launch_inv(e, mo, b, side);
+        e->stream = main;
+        if (rc) return rc;
+    }
+    OsGeo G;
+    G.hop = hop;
+    G.ovl = ovl;
+    G.n_in = (int64_t)T * MC_B;
+    G.tau0 = (int64_t)e->t_front * MC_B;
+    G.seg0 = 0;
+    hipLaunchKernelGGL(k_os_cols, dim3(nseg * OS_TPS), dim3(OS_THREADS), 0, main, d_in1, d_in2, (const float*)e->d_xhist, e->xr, G, e->d_os_T,
+                       e->cfg.compat ? e->d_os_part : (float4*)nullptr, e->d_tw);
+    if (side != main) {
+        HIP_TRY(hipEventRecord(e->os_ev[1], main));
+        HIP_TRY(hipStreamWaitEvent(side, e->os_ev[1], 0));
+    }
+    {  // Q1/Q2 prefix sums of the batch from the column pass's partial sums, ahead of the output pass
+        CorrArgs ca;
+        std::memset(&ca, 0, sizeof(ca));
+        ca.sums = st.d_sums;
+        ca.parts = e->d_os_part;
+        ca.ptab = d_ptab;
+        ca.pstride = 0;
+        ca.T = T;
+        ca.vs = st.ctx.vs;
+        ca.inv_n = 1.0 / (double)e->cfg.n_ref;
+        ca.compat = (int)e->cfg.compat;
+        ca.cring = e->d_cring;
+        ca.rc = e->rc;
+        ca.tabs0 = (int64_t)st.ctx.t0;
+        ca.ctot = e->d_ctot;
+        corr_chunks(&ca, T, 0, T, T);
+        hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, side, ca);
+        if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, side, ca);
+    }
+    if (side != main) HIP_TRY(hipEventRecord(e->os_ev[2], side));
+    if (e->ktiming && e->kev_n == kEvPool) {
+        rc = drain_kernel_events(e);
+        if (rc) return rc;
+    }
+    if (e->ktiming) {
+        e->kev_blocks[e->kev_n] = (uint32_t)T;
+        HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], main));
+    }
+    hipLaunchKernelGGL(k_os_rows, dim3(nseg * OS_ITEMS), dim3(G2B_THREADS), 0, main, e->d_os_T, (const float4*)e->d_os_SP, (const float4*)e->d_os_SP0, nseg);
+    if (e->ktiming) {
+        HIP_TRY(hipEventRecord(e->kev[e->kev_n][1], main));
+        e->kev_n++;
+        e->ks.resident = 1;
+        e->ks.partitions = (uint32_t)ovl_blocks;
+        e->ks.fast_levels = 253u;
+    }
+    if (side != main) HIP_TRY(hipStreamWaitEvent(main, e->os_ev[2], 0));  // (everything the side stream did: the output pass needs the prefix ring, later calls the rest)
+    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
+    {
+        OutArgs oa;
+        std::memset(&oa, 0, sizeof(oa));
+        oa.in1 = d_in1;
+        oa.in2 = d_in2;
+        oa.outL = d_outL;
+        oa.outR = d_outR;
+        oa.ptab = d_ptab;
+        oa.pstride = 0;
+        oa.cring = e->d_cring;
+        oa.rc = e->rc;
+        oa.tabs0 = (int64_t)st.ctx.t0;
+        oa.predelay = (int64_t)st.ctx.predelay;
+        oa.n_ref = (int64_t)e->cfg.n_ref;
+        oa.b0 = make_retired(e).b0;
+        oa.compat = (int)e->cfg.compat;
+        oa.pm = e->pm;
+        oa.out_from = head;
+        oa.out_end = T;
+        oa.out_blk0 = 0;
+        oa.blk0 = 0;
+        oa.wet_head = head;
+        oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));
+        hipLaunchKernelGGL(k_os_out, dim3(nseg * OS_TPS), dim3(OS_THREADS), 0, main, (const float4*)e->d_os_T, G, e->d_wet, e->wr, e->d_tw, oa);
+    }
+    HIP_TRY(hipGetLastError());
+    stored.out_from = head;
+    stored.corr_done = true;
+    e->n_os[0]++;
+    return MC_OK;
+}
+
 // forward transform + MAC + inverse + overlap-add; lin != null -> sharded partial.
 // first/count: the output blocks of the batch this engine will finish (block-sliced operation when count < T):
 // everything that later calls depend on (delay line, gains, Q1/Q2 sums, histories) is still produced for all T
@@ -1493,6 +1738,18 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     const int pstride = st.ctx.pstride;
 
     const int slot0 = (int)(e->t_front & (uint64_t)(e->ring - 1));
+
+    {  // long settled batches: overlap-save segments instead of the three passes below (ossave.hip.h)
+        int os_ovl = 0;
+        if (!slice && !lin && !piped && to_wet && os_applies(e, st, T, d_in1, d_in2, d_outL, d_outR, &os_ovl)) {
+            const int rc = run_os(e, st, e->pipe[(e->pipe_head + e->pipe_count) % kPipe], d_in1, d_in2, d_outL, d_outR, T, os_ovl, slot0);
+            if (rc) return rc;
+            e->pipe_count++;
+            e->batch_seq++;
+            e->t_front += (uint64_t)T;
+            return MC_OK;
+        }
+    }
 
     // K1: the blocks this engine can reach (all T unless block-sliced).  The input history ring serves the Q8 pass of
     // LATER calls (a batch reads its own samples from its input buffers): they look back less than one reference
@@ -2877,6 +3134,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     if (const char* fo = std::getenv("MCCONV_DROP_AHEAD")) e->drop_ahead = std::atoi(fo) != 0;
     if (const char* fo = std::getenv("MCCONV_CARRY_DROP")) e->carry_drop = std::atoi(fo) != 0;
     if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
+    if (const char* os = std::getenv("MCCONV_OS")) e->os_on = std::atoi(os) != 0;
+    if (const char* os = std::getenv("MCCONV_OS_SIDE")) e->os_side = std::atoi(os) != 0;
+    if (const char* os = std::getenv("MCCONV_OS_MIN")) e->os_min_blocks = std::max(1, std::atoi(os));
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
@@ -2953,6 +3213,16 @@ void mc_destroy(mc_engine* e) {
     (void)hipFree(e->d_res_mac);
     (void)hipFree(e->d_res_fix);
     (void)hipFree(e->d_xhist);
+    (void)hipFree(e->d_os_T);
+    (void)hipFree(e->d_os_part);
+    (void)hipFree(e->d_os_SP);
+    (void)hipFree(e->d_os_SP0);
+    (void)hipFree(e->d_os_planes);
+    if (e->os_stream) {
+        (void)hipStreamSynchronize(e->os_stream);
+        for (int i = 0; i < 3; i++) (void)hipEventDestroy(e->os_ev[i]);
+        (void)hipStreamDestroy(e->os_stream);
+    }
     (void)hipFree(e->d_gring);
     (void)hipFree(e->d_ptab);
     (void)hipFree(e->d_tw);
@@ -3048,6 +3318,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     }
     ir.d_h = reinterpret_cast<float2*>(d_lr);  // the truncated taps stay on the device for the Q8 pass
     invalidate_derived(ir);
+    e->ir_gen++;
     for (int l = 0; l < 3; l++)  // (a reloaded IR gives its fast-FIR components back; the stream is idle here)
         if (ir.d_Hp[l]) {
             (void)hipFree(ir.d_Hp[l]);
@@ -3335,6 +3606,11 @@ uint64_t mc_preferred_batch(const mc_engine* e, uint64_t at_most) {
         pmax = pe - pb;
     }
     uint64_t chunk = 0;
+    // overlap-save segments of 16384 - P16 blocks (ossave.hip.h): whole segments waste nothing
+    if (e->os_on && !e->half && !e->pipelined && !shard && pmax > 0 && (int64_t)pmax * MC_B <= OS_N / 2) {
+        const uint64_t hopb = (uint64_t)(OS_N / MC_B - pmax);
+        if (at_most >= hopb && at_most >= (uint64_t)e->os_min_blocks) return at_most / hopb * hopb;
+    }
     if (e->fft2 && !e->half && (shard ? pmax >= 16 : pmax >= e->g2_pmin)) {
         if (e->fft2_fused && pmax <= e->g2_pmax) chunk = (uint64_t)(G2_N - pmax + 1);
         else if (pmax <= F2_N / 2) chunk = (uint64_t)(F2_N - pmax + 1);
@@ -3378,6 +3654,11 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         std::memcpy(dst, reinterpret_cast<const char*>(e->n_mac_form) + off, bytes);
         return MC_OK;
     }
+    if (which == 11) {  // overlap-save form: {batches that took it, spectra builds}: no stream access
+        if (off + bytes > sizeof(e->n_os)) return fail(MC_ERR_ARG, "read beyond the counters");
+        std::memcpy(dst, reinterpret_cast<const char*>(e->n_os) + off, bytes);
+        return MC_OK;
+    }
     if (which == 9) {  // Q8 regime, batches: {cut terms summed by k_drop_fft for the whole batch, by the forward transforms (k_fwd<true>), in the time domain}: no stream access
         const uint64_t c[4] = {e->n_drop_fft, e->n_drop_ahead, e->n_drop_tiles, e->n_drop_carried};
         if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
@@ -3403,6 +3684,9 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
         case 3: src = (const char*)e->d_seg; cap = sizeof(float) * (uint64_t)e->sr * 2 * FFT_N; break;
         case 4: src = (const char*)e->d_wet; cap = sizeof(float) * 2 * (uint64_t)e->wr; break;
         case 5: src = (const char*)e->d_cring; cap = sizeof(double) * 4 * (uint64_t)e->rc; break;
+        case 12: src = (const char*)e->d_os_T; cap = sizeof(float4) * (uint64_t)OS_ITEMS * OS_N2 * e->os_T_segs; break;
+        case 13: src = (const char*)e->d_os_SP; cap = e->d_os_SP ? sizeof(float4) * (uint64_t)OS_ITEMS * OS_N2 * 2 : 0; break;
+        case 14: src = (const char*)e->d_os_SP0; cap = e->d_os_SP0 ? sizeof(float4) * 2 * (uint64_t)OS_N2 : 0; break;
         default: return fail(MC_ERR_ARG, "unknown buffer %d", which);
     }
     if (off + bytes > cap) return fail(MC_ERR_ARG, "read beyond buffer (%llu + %llu > %llu)", (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)cap);

@@ -273,6 +273,13 @@ class Convolution:
         check(self._L.mc_debug_read(self._h, 10, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
         return dict(fused=int(a[0]), split=int(a[1]), resident=int(a[2]))
 
+    def os_stats(self):
+        """Batches that took the overlap-save form of long settled batches and builds of its spectra (mc_debug_read
+        item 11; host-side counters)."""
+        a = np.zeros(2, np.uint64)
+        check(self._L.mc_debug_read(self._h, 11, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return dict(batches=int(a[0]), spectra_builds=int(a[1]))
+
     def param_generation(self, published=False):
         """Generation number of the parameter pair the last process call ran on (published=True: of the pair
         published last).  Every mc_set_params / mc_handle_cc publishes a new pair (csrc/params_handoff.h)."""

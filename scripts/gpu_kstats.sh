@@ -8,7 +8,7 @@ for v in "$@"; do
     python3 - "$OUT" "$v" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv')[0]
-print('[%s]' % sys.argv[2], ' '.join('%s %.1f' % (r['Name'].split('(')[0].replace('void ','')[:12], float(r['AverageNs']) / 1e3) for r in list(csv.DictReader(open(f)))[:5]))
+print('[%s]' % sys.argv[2], ' '.join('%s %.1f' % (r['Name'].split('(')[0].replace('void ','')[:14], float(r["AverageNs"]) / 1e3) for r in list(csv.DictReader(open(f)))[:9]))
 PY
     find $OUT -name "*_kernel_trace.csv" -delete )
 done
