@@ -255,6 +255,21 @@ def second_level_bytes(blk, taps, fused):
             "chunks": nchunk}
 
 
+def overlap_save_bytes(blk, taps16):
+    """Compulsory HBM bytes of the three passes of the overlap-save form (csrc/ossave.hip.h) over `blk` blocks: segments of
+    16384 - P16 blocks, each a 512 x 8192-point transform whose rows pass through memory twice (8 B per point)."""
+    N = 512 * 8192
+    hop = N // 256 - taps16
+    nseg = -(-blk // hop)
+    inter = 8 * N * nseg                       # the segment between two passes: one complex number per frame
+    spectra = 2 * 16 * N // 2 + 2 * 16 * 8192  # {A, B} per bin: 256 row pairs x 8192 x 32 B, + rows 0 and 256
+    cols = {"input": 8 * N * nseg, "rows_out": inter, "block_sum_parts": 16 * 512 * 512 * nseg}
+    rows = {"rows_in": inter, "spectra": spectra, "rows_out": inter}
+    out = {"rows_in": inter, "dry_input": 8 * 256 * blk, "output": 8 * 256 * blk}
+    return {"segments": nseg, "blocks_per_segment": hop, "k_os_cols": cols, "k_os_rows": rows, "k_os_out": out,
+            "rows_total": sum(rows.values()), "total": sum(cols.values()) + sum(rows.values()) + sum(out.values())}
+
+
 def labelled_profile(name, key=None):
     """A number copied from a committed profile is labelled as such: {value..., from, commit}.  None if absent."""
     path = os.path.join(ROOT, "profiles", name)
@@ -636,6 +651,8 @@ def main():
                 got = d_out[0].cpu().numpy()
                 chunk = None
                 lv = int(ks.get("fast_levels", 0))
+                if lv == 253:
+                    chunk = 16384 - int(ks["partitions"])  # overlap-save form: blocks per segment
                 if lv in (254, 255):
                     chunk = (8192 if lv == 254 else 16384) - int(ks["partitions"]) + 1
                 where = [(0, 64)]  # first blocks of the launch: their windows and overlap-add reach into the previous step
@@ -1003,7 +1020,7 @@ def main():
             kept = None
             if world > 1:
                 dist.barrier()
-        res["sum_over_partitions"] = {254: "second-level transform, fused form (k_g2_mac)", 255: "second-level transform, split form",
+        res["sum_over_partitions"] = {253: "overlap-save segments (k_os_cols, k_os_rows, k_os_out)", 254: "second-level transform, fused form (k_g2_mac)", 255: "second-level transform, split form",
                                       0: "direct-form MAC"}.get(lv, str(lv))
         eng.close()
         return res
@@ -1086,6 +1103,39 @@ def main():
                                 + ") / kernel time. The kernel is a second-level transform along the block axis (per bin one circular "
                                 "convolution per chunk of blocks), not the partition x bin MAC of SURVEY 8(d); survey_8d_accounting "
                                 "prices it that way for reference.")
+        elif ks["resident"] and lv == 253:
+            cb = overlap_save_bytes(blk, int(ks["partitions"]))
+            gbs = cb["rows_total"] / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+            tr = labelled_profile("r4_hbm_traffic.json", "headline")
+            traffic = None
+            if tr:
+                rec = [v for k, v in tr["data"].items() if "k_os_rows" in k]
+                tr["data"] = rec
+                if rec and all(int(v.get("blocks_per_launch", -1)) == int(blk) for v in rec):
+                    traffic = sum(int(v["hbm_bytes_per_launch"]) for v in rec)
+            roofline = dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_os_rows"}, **common)
+            roofline["algorithmic_bytes_per_launch"] = cb["rows_total"]
+            roofline["algorithmic_bytes"] = cb
+            if tr and traffic is not None:
+                roofline["traffic_source"] = {k: tr[k] for k in ("from", "commit", "note")}
+            step_ms = dt / a.steps * 1e3
+            step_bytes = cb["total"] * npairs * max(1, -(-T // max(blk, 1)))
+            roofline["whole_step"] = {"compulsory_bytes": step_bytes, "ms": round(step_ms, 4),
+                                      "achieved": round(step_bytes / (step_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                      "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "input_plus_output_bytes": 16 * 256 * T * npairs,
+                                      "note": "compulsory bytes of the three passes of a step (column pass: both inputs in incl. each "
+                                              "segment's history, the segment's rows out; row pass: rows in and out, the spectra once; output "
+                                              "pass: rows and dry input in, both channels out) / wall time per step, launch gaps and the small "
+                                              "launches on the side stream included.  input_plus_output_bytes is what a single pass would move."}
+            roofline["survey_8d_accounting"] = survey
+            roofline["direct_form_equivalent_tflops"] = round(achieved_tf, 2)
+            roofline["note"] = ("achieved = COMPULSORY bytes of the row pass (every row of every segment in and out once, the spectra once) / "
+                                "kernel time. The batch runs as overlap-save segments of 512 x 8192 frames (one whole-IR spectrum product per "
+                                "segment, as the reference's own algorithm does per call, conv.cu:367-408), not as the partition x bin MAC of "
+                                "SURVEY 8(d); survey_8d_accounting prices it that way for reference. MCCONV_OS=0 selects the second-level-"
+                                "transform path of round 3 (k_g2_mac), --mode stream the literal MAC.")
         elif ks["resident"]:
             roofline = dict({"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_mac_resident"}, **common)

@@ -1216,7 +1216,8 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
 // (5 us each as kernels: launch and drain latency, not work).
 struct CorrArgs {
     const float4* sums;
-    const float4* parts;  // != null: sums[t] = the sum of the sixteen partial sums parts[16 t ..] (the column pass of ossave.hip.h)
+    const float4* parts;  // != null: sums[t] = the sum of sixteen partial sums the column pass of ossave.hip.h left, [segment][512 tiles][512 rows]:
+    int parts_hop, parts_ovl;  // block t lies parts_ovl + t % parts_hop blocks into segment t / parts_hop, i.e. in row n1 of the sixteen tiles from n2 / 16 on
     const BlockParams* ptab;
     int pstride, T;
     VoiceSums vs;
@@ -1262,10 +1263,11 @@ __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], con
     if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0)) {
         float4 sa;
         if (A.parts) {  // sixteenths in frame order, summed pairwise
-            const float4* q = A.parts + (size_t)t * 16;
+            const int sg = t / A.parts_hop, nb = A.parts_ovl + t % A.parts_hop;  // 32 blocks per row of 8192 frames
+            const float4* q = A.parts + ((size_t)sg * 512 + (size_t)(nb & 31) * 16) * 512 + (nb >> 5);
             float4 h[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) h[i] = q[i];
+            for (int i = 0; i < 16; i++) h[i] = q[(size_t)i * 512];
 #pragma unroll
             for (int w = 8; w > 0; w >>= 1)
 #pragma unroll

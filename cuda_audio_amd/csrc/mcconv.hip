@@ -322,7 +322,8 @@ struct mc_engine {
     int os_min_blocks = 12288;  // shortest batch that takes the form (a segment costs the same however little of it is used)
     float4* d_os_T = nullptr;   // [segments][256 row pairs][8192] {row k1, row 512 - k1} between the passes
     size_t os_T_segs = 0;
-    float4* d_os_part = nullptr;  // [Tmax][16] sixteenths of the blocks' sums {S1, S2, A1, A2}
+    float4* d_os_part = nullptr;  // [segments][512 tiles][512] the tiles' sixteenths of the blocks' sums {S1, S2, A1, A2}
+    size_t os_part_segs = 0;
     float4 *d_os_SP = nullptr, *d_os_SP0 = nullptr;  // spectra A, B of the cached key, in the row pass's order
     float* d_os_planes = nullptr;  // gain-weighted taps, four planes of os_planes_n floats
     size_t os_planes_n = 0;
@@ -1468,8 +1469,15 @@ int ensure_os(mc_engine* e, const Staged& st, int nseg) {
         HIP_TRY(hipMalloc(&e->d_os_T, sizeof(float4) * seg_el * want));
         e->os_T_segs = want;
     }
-    if (!e->d_os_part) HIP_TRY(hipMalloc(&e->d_os_part, sizeof(float4) * 16 * (size_t)e->Tmax));
-    if (e->os_side && !e->os_stream) {
+    if (e->os_part_segs < (size_t)nseg) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_os_part) (void)hipFree(e->d_os_part);
+        e->d_os_part = nullptr;
+        e->os_part_segs = 0;
+        HIP_TRY(hipMalloc(&e->d_os_part, sizeof(float4) * (size_t)OS_TPS * OS_N1 * (size_t)nseg));
+        e->os_part_segs = (size_t)nseg;
+    }
+    if (!e->os_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&e->os_stream, hipStreamNonBlocking));
         for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreateWithFlags(&e->os_ev[i], hipEventDisableTiming));
     }
@@ -1545,10 +1553,8 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
     if (rc) return rc;
     const BlockParams* d_ptab = st.d_ptab;
     const hipStream_t main = e->stream, side = e->os_side ? e->os_stream : e->stream;
-    if (side != main) {  // the side stream starts where the engine's stream stands
-        HIP_TRY(hipEventRecord(e->os_ev[0], main));
-        HIP_TRY(hipStreamWaitEvent(side, e->os_ev[0], 0));
-    }
+    HIP_TRY(hipEventRecord(e->os_ev[0], main));  // the side stream and the work streams start where the engine's stream stands
+    if (side != main) HIP_TRY(hipStreamWaitEvent(side, e->os_ev[0], 0));
     // state for later calls: delay line, slot gains, input / gain histories of the last blocks (what any later window,
     // Q8 pass or re-render of a predelay epoch can reach), and the last block's segment as the partitioned passes leave it
     // (its partition sums from the delay line, one inverse transform: its second half opens the next call)
@@ -1569,6 +1575,29 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         e->stream = main;
         if (rc) return rc;
     }
+    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
+    OutArgs oa;
+    std::memset(&oa, 0, sizeof(oa));
+    oa.in1 = d_in1;
+    oa.in2 = d_in2;
+    oa.outL = d_outL;
+    oa.outR = d_outR;
+    oa.ptab = d_ptab;
+    oa.pstride = 0;
+    oa.cring = e->d_cring;
+    oa.rc = e->rc;
+    oa.tabs0 = (int64_t)st.ctx.t0;
+    oa.predelay = (int64_t)st.ctx.predelay;
+    oa.n_ref = (int64_t)e->cfg.n_ref;
+    oa.b0 = make_retired(e).b0;
+    oa.compat = (int)e->cfg.compat;
+    oa.pm = e->pm;
+    oa.out_from = head;
+    oa.out_end = T;
+    oa.out_blk0 = 0;
+    oa.blk0 = 0;
+    oa.wet_head = head;
+    oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));
     OsGeo G;
     G.hop = hop;
     G.ovl = ovl;
@@ -1586,6 +1615,8 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         std::memset(&ca, 0, sizeof(ca));
         ca.sums = st.d_sums;
         ca.parts = e->d_os_part;
+        ca.parts_hop = hop_blocks;
+        ca.parts_ovl = ovl_blocks;
         ca.ptab = d_ptab;
         ca.pstride = 0;
         ca.T = T;
@@ -1618,32 +1649,7 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         e->ks.fast_levels = 253u;
     }
     if (side != main) HIP_TRY(hipStreamWaitEvent(main, e->os_ev[2], 0));  // (everything the side stream did: the output pass needs the prefix ring, later calls the rest)
-    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
-    {
-        OutArgs oa;
-        std::memset(&oa, 0, sizeof(oa));
-        oa.in1 = d_in1;
-        oa.in2 = d_in2;
-        oa.outL = d_outL;
-        oa.outR = d_outR;
-        oa.ptab = d_ptab;
-        oa.pstride = 0;
-        oa.cring = e->d_cring;
-        oa.rc = e->rc;
-        oa.tabs0 = (int64_t)st.ctx.t0;
-        oa.predelay = (int64_t)st.ctx.predelay;
-        oa.n_ref = (int64_t)e->cfg.n_ref;
-        oa.b0 = make_retired(e).b0;
-        oa.compat = (int)e->cfg.compat;
-        oa.pm = e->pm;
-        oa.out_from = head;
-        oa.out_end = T;
-        oa.out_blk0 = 0;
-        oa.blk0 = 0;
-        oa.wet_head = head;
-        oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));
-        hipLaunchKernelGGL(k_os_out, dim3(nseg * OS_TPS), dim3(OS_THREADS), 0, main, (const float4*)e->d_os_T, G, e->d_wet, e->wr, e->d_tw, oa);
-    }
+    hipLaunchKernelGGL(k_os_out, dim3(nseg * OS_TPS), dim3(OS_THREADS), 0, main, (const float4*)e->d_os_T, G, e->d_wet, e->wr, e->d_tw, oa);
     HIP_TRY(hipGetLastError());
     stored.out_from = head;
     stored.corr_done = true;

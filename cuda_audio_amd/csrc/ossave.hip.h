@@ -102,10 +102,10 @@ __device__ __forceinline__ void os_twiddles(int n2, int lane, v2f (&w)[8]) {
 // Column pass.  grid = segments x 512 tiles, block = 1024 (16 wavefronts = 16 columns n2).
 // A tile reads, for each n1, 16 consecutive frames of both inputs (64 bytes each) - from the batch's buffers, from the
 // input-history ring where the segment reaches back before the batch (xhist != null), zero beyond the batch - and writes
-// 256 bytes per item row.  part != null: the tile's sixteenth of each block's sums {S1, S2, A1, A2} for the frames the
-// segment owns.
+// 256 bytes per item row.  part != null: the tile's sixteenth of the sums {S1, S2, A1, A2} of the block each row lies in,
+// part[(seg 512 + tile) 512 + n1] (256 contiguous bytes per wave and store; CorrArgs::parts gathers a block's sixteen).
 // Bounds: src frames are tested against [0, n_in); the ring index is masked; Tbuf[(seg 256 + item) 8192 + n2], seg <
-// gridDim.x / 512, item < 256, n2 < 8192; part[16 t + j], t = src >> 8 < n_in / 256.
+// gridDim.x / 512, item < 256, n2 < 8192; part index < segments 512 512.
 // LDS: the staging tile [512][17] float2, the 16 transform buffers and the transposed tile [256][17] float4 share one
 // 74 KB region (two workgroups per CU).
 // ---------------------------------------------------------------------------
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_cols(const float* __restrict_
             float d1 = (a.x - a.y) + (a.z - a.w), d2 = (b.x - b.y) + (b.z - b.w);
             s1 += __shfl_xor(s1, 1), s2 += __shfl_xor(s2, 1), d1 += __shfl_xor(d1, 1), d2 += __shfl_xor(d2, 1);
             s1 += __shfl_xor(s1, 2), s2 += __shfl_xor(s2, 2), d1 += __shfl_xor(d1, 2), d2 += __shfl_xor(d2, 2);
-            // the segment owns the frames behind its history that lie inside the batch
-            if (q == 0 && (int64_t)OS_N2 * n1 + n2_0 >= G.ovl && src < G.n_in) part[(size_t)(src >> 8) * 16 + (size_t)((src & 255) >> 4)] = make_float4(s1, s2, d1, d2);
+            // (every row is written; the prefix kernels read the rows of the blocks the segment owns)
+            if (q == 0) part[((size_t)segl * OS_TPS + tile) * OS_N1 + n1] = make_float4(s1, s2, d1, d2);
         }
     }
     __syncthreads();

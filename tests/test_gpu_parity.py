@@ -1585,6 +1585,16 @@ def test_preferred_batch_length(gpu_lib, monkeypatch):
 
     monkeypatch.setenv("MCCONV_FFT2", "1")  # (the suite is also run with the measurement switches set)
     monkeypatch.setenv("MCCONV_FFT2_FUSED", "1")
+    # with the overlap-save form on (the default): whole segments of 16384 - P16 blocks once a batch can take the form
+    monkeypatch.setenv("MCCONV_OS", "1")
+    c = _conv(fftSize=524288, max_batch=40000)
+    c.prepare(0, make_ir(441000, seed=1))   # 1723 partitions -> 1728: segments of 14656 blocks
+    assert c.preferred_batch(32768) == 2 * 14656
+    assert c.preferred_batch(20000) == 14656
+    assert c.preferred_batch(14000) == 12928  # shorter than a segment: the second-level transform's chunks (two of 6465, minus one, to 8)
+    assert c.preferred_batch(6000) == 6000
+    c.close()
+    monkeypatch.setenv("MCCONV_OS", "0")  # the rest of this test: the second-level transform's chunks
 
     c = _conv(fftSize=524288, max_batch=40000)
     assert c.preferred_batch(1000) == 1000  # nothing loaded: no preference
@@ -1630,6 +1640,7 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
         monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")
         monkeypatch.setenv("MCCONV_FFT2_FUSED", "1" if fused else "0")
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
+        monkeypatch.setenv("MCCONV_OS", "0")  # (the longest batches here would take the overlap-save form: tested on its own below)
         c = _conv(fftSize=n_ref, max_batch=max(sizes))
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
@@ -1672,8 +1683,11 @@ def test_second_level_transform_of_long_batches(oracle_mod, gpu_lib, monkeypatch
 
 @pytest.mark.parametrize("n_ref,taps,level,direct_cmp,at_most",
                          [(524288, 441000, 254, True, 32768), (2097152, 1323000, 255, False, 32768),
-                          (2097152, 1323000, 254, False, 32768), (524288, 441000, 254, False, 131072)],
-                         ids=["P1723_fused", "P5168_split", "P5168_fused", "P1723_fused_bench_step"])
+                          (2097152, 1323000, 254, False, 32768), (524288, 441000, 254, False, 131072),
+                          (524288, 441000, 253, True, 32768), (2097152, 1323000, 253, False, 32768),
+                          (524288, 441000, 253, False, 131072)],
+                         ids=["P1723_fused", "P5168_split", "P5168_fused", "P1723_fused_bench_step",
+                              "P1723_overlap_save", "P5168_overlap_save", "P1723_overlap_save_bench_step"])
 def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, level, direct_cmp, at_most):
     """The launch bench.py times (its step: mc_preferred_batch(131072) = 129296 blocks, twenty chunks - the last case),
     compared DIRECTLY with the oracle (conv.cu:392-401 restated as the partitioned sum,
@@ -1682,7 +1696,10 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
     look-ahead; 22432 = two chunks of the split 16384-point form for the 30 s IR - in steady state (second and third
     batch of the stream; the 30 s IR also through the fused form, ten chunks of 3025 blocks, which it takes by
     default since round 2's kernel made it the faster one there).  Oracle blocks: inside chunk 0, across the first chunk boundary, the batch end and the
-    first blocks of the next launch.  For the 10 s IR also the whole batch against the direct-form MAC."""
+    first blocks of the next launch.  For the 10 s IR also the whole batch against the direct-form MAC.
+    Level 253 (round 4, the default for these batches): the overlap-save form of csrc/ossave.hip.h - segments of
+    16384 - P16 blocks through one 512 x 8192-point transform each; bench.py's step is then eight segments = 117248 blocks.
+    Oracle blocks: inside segment 0, across the first segment boundary, the batch end and the next launch's first blocks."""
     import torch
 
     from cuda_audio_amd.synth import make_input, make_ir
@@ -1695,6 +1712,7 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         monkeypatch.setenv("MCCONV_FFT2", "0" if direct else "1")  # (the suite is also run with the measurement switches set)
         monkeypatch.setenv("MCCONV_FFT2_FUSED", "1" if level == 254 else "0")
         monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
+        monkeypatch.setenv("MCCONV_OS", "1" if level == 253 and not direct else "0")
         c = _conv(fftSize=n_ref, max_batch=at_most)
         for i, ir in enumerate(irs):
             c.prepare(i, ir)
@@ -1715,10 +1733,15 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         return x, T, out, levels
 
     x, T, got, levels = run(False)
-    assert T == ((129296 if at_most > 32768 else 32320) if taps == 441000 else (30248 if level == 254 else 22432))
+    p16 = -(-((taps + 255) // 256) // 16) * 16
+    if level == 253:
+        chunk = 16384 - p16  # blocks per segment
+        assert T == at_most // chunk * chunk and T == ((117248 if at_most > 32768 else 29312) if taps == 441000 else 22432)
+    else:
+        assert T == ((129296 if at_most > 32768 else 32320) if taps == 441000 else (30248 if level == 254 else 22432))
+        chunk = (8192 if level == 254 else 16384) - p16 + 1
+        assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
     assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
-    chunk = (8192 if level == 254 else 16384) - (-(-((taps + 255) // 256) // 16) * 16) + 1
-    assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
     ranges = [(T + 100, 256), (T + chunk - 65, 130), (2 * T - 128, 128 + 64)]  # (first block, blocks) in the stream
     num = den = 0.0
     for b0, n in ranges:
@@ -1741,6 +1764,136 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         assert lv[1] == 0
         d = rms(got[1] - ref[1])
         assert 0 < d <= 2e-6, f"second-level transform vs direct-form MAC over the whole {T}-block batch: {d:.3e}"
+
+
+@pytest.mark.parametrize("n_ref,taps,case", [(131072, (88200, 80000), "aligned"), (131072, (88200, 80000), "odd_predelay"),
+                                             (524288, (441000, 400000), "aligned")], ids=["P345", "P345_odd_predelay", "P1723"])
+def test_overlap_save_batches_match_the_partitioned_passes(oracle_mod, gpu_lib, monkeypatch, n_ref, taps, case):
+    """Round 4: whole batches of >= 12288 blocks whose window carries one set of gains run as overlap-save segments of
+    16384 - P16 blocks (csrc/ossave.hip.h: one 512 x 8192-point transform per segment instead of zero-padded 512-point
+    blocks and a second transform along the block axis).  The same stream through both forms (MCCONV_OS=0: the
+    partitioned passes, which the other tests hold to the oracle): batches that are whole segments, ragged (a segment
+    and a bit, a last segment nearly empty), right after a gain change (that batch's window carries two sets of gains:
+    partitioned passes; the next one takes the form again with new spectra), after a select with a cross-fade (per-block
+    gains, then two voices with one set of gains each folded into ONE pair of spectra), an unaligned predelay (the output
+    stage frame by frame), and what follows a batch in this form - a short batch (resident MAC on the delay-line slots
+    the form left) and single JACK periods (segment ring, wet ring, prefix ring).  Steady stretches also against the
+    range oracle directly."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    p16 = -(-((taps[0] + 255) // 256) // 16) * 16
+    hop = 16384 - p16
+    sizes = [700, hop, hop + 1237, 2 * hop + 8, 12288, 13001, 13000, 12500, 12400, 600]
+    nper = 6
+    nb = sum(sizes) + nper
+    x = make_input(nb * 256)
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)] + [make_ir(taps[0] - 7000, seed=99, norm=0.02)]
+    pd = 1024 if case == "aligned" else 301
+    p0, p1 = dict(BASE, predelay=pd, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9, predelay=pd)
+
+    def run(os_on):
+        import torch
+
+        monkeypatch.setenv("MCCONV_OS", "1" if os_on else "0")
+        monkeypatch.setenv("MCCONV_FFA_LEVELS", "0")
+        c = _conv(fftSize=n_ref, max_batch=max(sizes))
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        dev = torch.device("cuda:0")
+        d_in = torch.from_numpy(x).to(dev)
+        d_out = torch.zeros(2, nb * 256, device=dev)
+        c.enable_kernel_timing(True)
+        levels, o = [], 0
+        for k, n in enumerate(sizes):
+            if k == 5:  # a gain change: this batch's window carries two sets of gains
+                c.cc[1].value.update(wet=0.3, panWet=-0.5)
+                c.cc[0].value.level = 0.8
+            if k == 7:  # a select: the cross-fade ramps per block, afterwards two voices sound in the windows
+                c.cc[0].value.update(select=2, vsteps=100)
+            c.process_device(d_in[0, o * 256:].data_ptr(), d_in[1, o * 256:].data_ptr(), d_out[0, o * 256:].data_ptr(), d_out[1, o * 256:].data_ptr(), n)
+            c.sync()
+            levels.append(c.kernel_stats()["fast_levels"])
+            o += n
+        out = d_out.cpu().numpy()
+        for j in range(nper):
+            a = (o + j) * 256
+            l, r = c.onProcess(x[0, a:a + 256], x[1, a:a + 256])
+            out[0, a:a + 256], out[1, a:a + 256] = l, r
+        st = c.os_stats()
+        c.close()
+        return out, levels, st
+
+    ref, lv0, st0 = run(False)
+    got, lv1, st1 = run(True)
+    assert st0["batches"] == 0 and 253 not in lv0
+    # batches 1-4 and 6 (one set of gains), 8 and 9 after the cross-fade has settled within the window or not: at least these
+    assert [lv1[k] for k in (1, 2, 3, 4, 6)] == [253] * 5, lv1
+    assert lv1[0] != 253 and lv1[5] != 253 and lv1[7] != 253, lv1  # cold-start ramp, gain change, cross-fade: per-slot gains
+    assert st1["batches"] >= 5 and st1["spectra_builds"] >= 2
+    o = 0
+    for k, n in enumerate(sizes + [nper]):
+        d = rms(got[:, o * 256:(o + n) * 256] - ref[:, o * 256:(o + n) * 256])
+        assert d <= 1e-6, f"batch {k} ({n} blocks, form {lv1[k] if k < len(lv1) else 'periods'}): {d:.3e} from the partitioned passes"
+        o += n
+    assert rms(got - ref) > 0
+    # steady stretches against the oracle itself: inside batch 2's second segment, the end of batch 3 and the start of batch 4
+    s1, s3 = sum(sizes[:2]), sum(sizes[:4])
+    for b0, n in [(s1 + hop - 40, 120), (s3 - 70, 140)]:
+        u = oracle_mod.Upols(n_ref, True)
+        for i, ir in enumerate(irs):
+            u.prepare(i, ir)
+        apply_params(u, p0, p1, True)
+        want = u.range(x[0], x[1], b0, n)
+        u.close()
+        err = rms(got[:, b0 * 256:(b0 + n) * 256] - want)
+        assert rms(want) > 0.01
+        assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"
+
+
+def test_overlap_save_form_keeps_out_of_the_q8_regime_and_of_retired_epochs(gpu_lib, monkeypatch):
+    """The form is for batches whose output is the plain sum over the window plus the Q1/Q2 terms: in the Q8 regime (taps + 255 +
+    predelay > n_ref: cut terms) and while a retired predelay epoch still rings out or lies inside the segments' history the
+    partitioned passes run - and the outputs agree with MCCONV_OS=0 either way."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, T = 131072, 13000
+    x = make_input(5 * T * 256)
+    irs = [make_ir(130048, seed=7, norm=0.02), make_ir(100000, seed=8, norm=0.02)]
+
+    def run(os_on):
+        monkeypatch.setenv("MCCONV_OS", "1" if os_on else "0")
+        c = _conv(fftSize=n_ref, max_batch=T)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, dict(BASE, predelay=1024), dict(BASE, select=0, predelay=1024), False)  # the shipped shape: Q8 regime
+        dev = torch.device("cuda:0")
+        d_in = torch.from_numpy(x).to(dev)
+        d_out = torch.zeros(2, 5 * T * 256, device=dev)
+        c.enable_kernel_timing(True)
+        lv = []
+        for k in range(5):
+            if k == 2:  # the shorter IR on both halves, no predelay: out of the regime, but the old epoch rings out / lies in the history
+                c.cc[0].value.update(select=1, predelay=0, vsteps=0)
+                c.cc[1].value.update(select=1, predelay=0, vsteps=0)
+            o = k * T * 256
+            c.process_device(d_in[0, o:].data_ptr(), d_in[1, o:].data_ptr(), d_out[0, o:].data_ptr(), d_out[1, o:].data_ptr(), T)
+            c.sync()
+            lv.append(c.kernel_stats()["fast_levels"])
+        out = d_out.cpu().numpy()
+        c.close()
+        return out, lv
+
+    ref, lv0 = run(False)
+    got, lv1 = run(True)
+    assert 253 not in lv0
+    assert lv1[0] != 253 and lv1[1] != 253 and lv1[2] != 253, lv1  # Q8 regime; then the batch of the change
+    assert lv1[4] == 253, lv1  # two batches later the window is settled and the old epoch out of reach
+    for k in range(5):
+        d = rms(got[:, k * T * 256:(k + 1) * T * 256] - ref[:, k * T * 256:(k + 1) * T * 256])
+        assert d <= 1e-6, f"batch {k}: {d:.3e}"
 
 
 def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
