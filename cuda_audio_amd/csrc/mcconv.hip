@@ -390,6 +390,9 @@ void ring_bell(mc_engine* e, unsigned seq, unsigned command) {
 // stream, or change what the parked tail has already loaded, it is told to give up.  It has written nothing; the next
 // mc_process launches that period again.
 void unpark(mc_engine* e) {
+    // (the cut terms a parked launch summed for the period after its own belong to that launch: without it - told to give up,
+    // or timed out and launched again, which rewrites the same buffer with ANOTHER block's terms - they are not to be trusted)
+    e->dspec.valid = false;
     if (e->pre.valid) {
         ring_bell(e, e->pre.seq, 1);
         e->pre.valid = false;
@@ -2225,6 +2228,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             ok = e->spec_vir[0][a] == st.ctx.vir[0][pl.sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][pl.sweep[a].v];
         return ok;
     };
+    int prep_rc = MC_OK;  // first failure of prepare_drop_fft inside tail_args (checked behind every launch that used it)
     auto tail_args = [&](const Staged& st, const Plan& pl, uint64_t blk, unsigned seq, bool parked) {
         TailArgs A;
         std::memset(&A, 0, sizeof(A));
@@ -2255,7 +2259,10 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         A.outL = e->hd_io + 2 * cap;
         A.outR = e->hd_io + 3 * cap;
         A.g_tw = e->d_tw;
-        (void)prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);  // (Q8 regime: the last partitions partition-major; without them the bank is read)
+        {  // (Q8 regime: the last partitions partition-major and the buffer of the cut terms)
+            const int r = prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
+            if (r != MC_OK && prep_rc == MC_OK) prep_rc = r;
+        }
         A.td = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
         A.fdl16 = e->d_fdl16;
         A.done_flag = e->hd_flag;
@@ -2340,6 +2347,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         e->spec_valid = false;
         my_seq = ++e->flag_seq;
         hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front, my_seq, false));
+        if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
@@ -2367,6 +2375,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             }
             const unsigned seq = ++e->flag_seq;
             TailArgs A = tail_args(st_next, pl_next, e->t_front, seq, true);
+            if (prep_rc) return prep_rc;
             SweepArgs S;
             std::memset(&S, 0, sizeof(S));
             const uint64_t blk2 = e->t_front + 1;  // the sweep this kernel carries
@@ -2461,6 +2470,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         }
         my_seq = ++e->flag_seq;
         hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front - 1, my_seq, false));
+        if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
 #ifdef MC_JACK_TRACE
@@ -2728,10 +2738,14 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
             ok = e->spec_vir[0][a] == st.ctx.vir[0][pl.sweep[a].v] && e->spec_vir[1][a] == st.ctx.vir[1][pl.sweep[a].v];
         return ok;
     };
+    int prep_rc = MC_OK;  // first failure of prepare_drop_fft inside launch_tail (checked behind every call)
     auto launch_tail = [&](const Staged& st, const PPlan& pl, uint64_t blk, unsigned seq, bool parked) {
         const int slot0 = (int)(blk & (uint64_t)(e->ring - 1));
         const unsigned long long* bell = parked ? (e->bar_io ? reinterpret_cast<unsigned long long*>(e->d_bar) : e->hd_bell) : nullptr;
-        (void)prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
+        {
+            const int r = prepare_drop_fft(e, st.ctx.vir, st.ctx.predelay);
+            if (r != MC_OK && prep_rc == MC_OK) prep_rc = r;
+        }
         const TailDrop tdp = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
         // Q8 regime: a parked tail sums its own cut terms while it waits for the period; one launched on arrival gets them from a launch ahead of it
         const bool self_drop = parked && tdp.on && tdp.fft && e->carry_drop;
@@ -2808,6 +2822,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         e->spec_valid = false;
         my_seq = ++e->flag_seq;
         launch_tail(st, pl, e->t_front, my_seq, false);
+        if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
     if (!e->spin_wait) HIP_TRY(hipEventRecord(e->ev_tail, e->stream));
@@ -2837,6 +2852,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
             }
             const unsigned seq = ++e->flag_seq;
             launch_tail(st_next, pl_next, e->t_front, seq, true);
+            if (prep_rc) return prep_rc;
             HIP_TRY(hipGetLastError());
             e->pre.valid = true;
             e->pre.pm = pm;
@@ -2865,6 +2881,7 @@ int process_period_fused(mc_engine* e, const float* in1, const float* in2, float
         if (rc) return rc;
         my_seq = ++e->flag_seq;
         launch_tail(st, pl, e->t_front - (uint64_t)pm, my_seq, false);
+        if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
     if (tio_p) {

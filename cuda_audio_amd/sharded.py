@@ -140,14 +140,18 @@ class HipShard:
 def reduce_scatter_channels(part2, ssum, rank, world, group=None):
     """Sum over ranks of the [2, n] partials, scattered by runs of blocks: rank r receives [2, n / world] = its run of
     both channel halves (one reduce-scatter per channel: a channel half is the concatenation of the ranks' runs).
-    Backends without a reduce-scatter on these tensors (gloo) take an all-reduce and keep their run."""
+    The path is chosen by the group's backend, the same on every rank, and errors propagate (a rank that fell back on its
+    own would issue a different collective from the others): nccl (= RCCL) takes reduce_scatter_tensor; gloo, which has
+    no reduce-scatter, an all-reduce of which every rank keeps its run.  The RCCL branch has run on one rank only so far
+    (no multi-GPU node has been available: DESIGN section 6)."""
     import torch.distributed as dist
 
     n = part2.shape[1] // world
+    backend = str(dist.get_backend(group)).lower()
     for c in range(2):
-        try:
+        if "nccl" in backend:
             dist.reduce_scatter_tensor(ssum[c], part2[c], op=dist.ReduceOp.SUM, group=group)
-        except (RuntimeError, NotImplementedError):
+        else:
             tmp = part2[c].clone()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
             ssum[c].copy_(tmp[rank * n:(rank + 1) * n])

@@ -536,6 +536,46 @@ def test_q8_parked_periods_carry_the_next_periods_cut_terms(oracle_mod, gpu_lib)
         assert parks["used"] > 40 and stats["carried_periods"] > 40, (stats, parks)
 
 
+def test_q8_carried_cut_terms_do_not_survive_a_park_timeout(oracle_mod, gpu_lib, monkeypatch):
+    """Round-3 advice (medium): in the Q8 regime the launch parked for period b also sums the cut terms of period b + 2 into the
+    buffer of b's parity.  When the host stays away longer than the park time, the tail of b gives up and is launched again -
+    and that launch's own cut terms (k_drop_period_fft for block b) overwrite the same buffer, while the engine still held the
+    carried terms of b + 2 to be valid: two calls later b + 2 was finished with b's terms (wrong by a whole Q8 term).  unpark()
+    now forgets the carried terms.  Settled stream, pauses of 60 ms against a park time of 20 ms, the oracle's samples throughout."""
+    import time
+
+    from cuda_audio_amd.synth import make_input
+
+    monkeypatch.setenv("MCCONV_PARK_MS", "20")
+    n_ref, L, nb = 4096, 3072, 260
+    x = make_input(nb * 256, seed=57)
+    rng = np.random.default_rng(61)
+    h = rng.standard_normal((L, 2)) * np.exp(-np.arange(L) / (2.0 * L))[:, None]
+    ir = (h * np.sqrt(0.004 / L)).astype(np.float32)
+    p0, p1 = dict(BASE, predelay=1024), dict(BASE, level=0.9)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    c = _conv(fftSize=n_ref, max_batch=8)
+    ref.prepare(0, ir)
+    c.prepare(0, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    got = np.zeros((2, nb * 256), np.float32)
+    want = np.zeros((2, nb * 256))
+    for b in range(nb):
+        if b in (200, 215, 230):
+            time.sleep(0.06)
+        s = slice(b * 256, (b + 1) * 256)
+        want[:, s] = ref.process(x[0, s], x[1, s])
+        got[0, s], got[1, s] = c.onProcess(x[0, s], x[1, s])
+    stats, parks = c.drop_stats(), c.park_stats()
+    c.close()
+    per_block = np.sqrt(((got - want) ** 2).reshape(2, nb, 256).mean(axis=(0, 2)))
+    assert per_block.max() <= 2 * RMS_TOL, f"worst block {int(per_block.argmax())}: {per_block.max():.3e} {stats} {parks}"
+    assert rms(got - want) <= RMS_TOL
+    if not any(os.environ.get(k) for k in ("MCCONV_NO_PARK", "MCCONV_NO_SPECULATE", "MCCONV_NO_SPIN", "MCCONV_TD_FFT", "MCCONV_CARRY_DROP")):
+        assert parks["timed_out"] >= 1 and stats["carried_periods"] > 10, (stats, parks)
+
+
 @pytest.mark.parametrize("period,pd", [(1024, 256), (512, 700), (1024, 0)])
 @pytest.mark.parametrize("jack", [False, True], ids=["batch", "jack"])
 def test_q8_begins_earlier_for_longer_calls(oracle_mod, gpu_lib, period, pd, jack):

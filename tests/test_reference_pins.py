@@ -26,7 +26,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), rea
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "ref"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "-B", "ref"])  # (always from the current sources: the outputs are not tracked)
     subprocess.check_call(["make", "-C", HOST, "-s", "mcconv_host_tool", "mcconv_host_stub"])
     return dict(ref=os.path.join(ROOT, "oracle", "_ref", "ref_settings_dump"), host=os.path.join(ROOT, "oracle", "_ref", "host_settings_dump"),
                 tool=os.path.join(HOST, "mcconv_host_tool"), stub=os.path.join(HOST, "mcconv_host_stub"))
