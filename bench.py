@@ -10,6 +10,7 @@ sum over partitions -> inverse FFT -> overlap-add -> predelay / Q1-Q2 terms /
 clamp / dry mix, inputs and outputs resident in HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts its N ranks itself, as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -338,8 +339,38 @@ def bench_params(h):
     return dict(select=0 if _BP["same_ir"] else h, predelay=_BP["predelay"], dry=0.5, wet=0.5, panDry=0.0, panWet=0.0, level=1.0, vsteps=0)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (torch.distributed.run as a
+    CHILD process on 127.0.0.1 and a free port), relay rank 0's JSON line and leave with the children's exit code.  This
+    process has not touched the GPU (torch is not even imported yet) and replaces nothing: it waits."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs between processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout:  # rank 0 prints ONE JSON line; anything else a library wrote to stdout goes to stderr
+        txt = raw.decode(errors="replace").rstrip("\n")
+        if txt.startswith("{") and txt.endswith("}"):
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc else (0 if line is not None else 1))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     if a.shipped_defaults:
         a.fft_size, a.taps, a.predelay, a.same_ir = 131072, 131072 - 1024, 1024, True
     _BP["predelay"], _BP["same_ir"] = a.predelay, a.same_ir
@@ -359,8 +390,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} rank(s)")
     if a.backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a card
         if a.collective == "reduce":

@@ -1217,7 +1217,8 @@ __device__ __forceinline__ void corr_terms(const float4 sa, const BlockParams& b
 struct CorrArgs {
     const float4* sums;
     const float4* parts;  // != null: sums[t] = the sum of sixteen partial sums the column pass of ossave.hip.h left, [segment][512 tiles][512 rows]:
-    int parts_hop, parts_ovl;  // block t lies parts_ovl + t % parts_hop blocks into segment t / parts_hop, i.e. in row n1 of the sixteen tiles from n2 / 16 on
+    int parts_hop, parts_ovl;  // with u = t - parts_t0: block t lies parts_ovl + u % parts_hop blocks into segment u / parts_hop (u < 0: parts_ovl + u blocks into
+    int parts_t0, parts_end;   // segment 0, its history), i.e. in row n1 of the sixteen tiles from n2 / 16 on; blocks >= parts_end take sums[t] (a block-sliced engine's tail run)
     const BlockParams* ptab;
     int pstride, T;
     VoiceSums vs;
@@ -1262,8 +1263,9 @@ __device__ __forceinline__ void corr_terms_body(int cb, double (*s_part)[4], con
     double d[4] = {0, 0, 0, 0};
     if (on && t < A.T && A.compat && ((t >= A.need_a0 && t < A.need_a1) || t >= A.need_b0)) {
         float4 sa;
-        if (A.parts) {  // sixteenths in frame order, summed pairwise
-            const int sg = t / A.parts_hop, nb = A.parts_ovl + t % A.parts_hop;  // 32 blocks per row of 8192 frames
+        if (A.parts && t < A.parts_end) {  // sixteenths in frame order, summed pairwise
+            const int u = t - A.parts_t0;
+            const int sg = u < 0 ? 0 : u / A.parts_hop, nb = A.parts_ovl + (u < 0 ? u : u % A.parts_hop);  // 32 blocks per row of 8192 frames
             const float4* q = A.parts + ((size_t)sg * 512 + (size_t)(nb & 31) * 16) * 512 + (nb >> 5);
             float4 h[16];
 #pragma unroll

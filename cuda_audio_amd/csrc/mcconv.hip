@@ -1442,21 +1442,23 @@ void corr_chunks(CorrArgs* ca, int T, int need_a0, int need_a1, int need_b0) {
 // ---------------------------------------------------------------------------
 // Can this whole batch take the form?  One fp32 engine finishing its own output, one set of gains over the batch and the
 // window before it, no Q8 pass, no retired predelay epoch ringing out, the segments' history inside the live epoch.
-bool os_applies(const mc_engine* e, const Staged& st, int T, const float* d_in1, const float* d_in2, const float* d_outL,
+bool os_applies(const mc_engine* e, const Staged& st, int count, bool slice, const float* d_in1, const float* d_in2, const float* d_outL,
                 const float* d_outR, int* ovl_blocks) {
-    if (!e->os_on || e->half || e->pipelined || !e->fuse_out || !e->inv_to_wet || e->sliced) return false;
-    if (e->cfg.part_begin || e->cfg.part_end || !d_outL || !d_outR || T < e->os_min_blocks || st.ctx.pstride != 0 || st.nact <= 0) return false;
+    if (!e->os_on || e->half || e->pipelined || !e->fuse_out || !e->inv_to_wet || (e->sliced && !slice)) return false;
+    if (e->cfg.part_begin || e->cfg.part_end || !d_outL || !d_outR || count < e->os_min_blocks || st.ctx.pstride != 0 || st.nact <= 0) return false;
     if ((reinterpret_cast<uintptr_t>(d_in1) | reinterpret_cast<uintptr_t>(d_in2) | reinterpret_cast<uintptr_t>(d_outL) | reinterpret_cast<uintptr_t>(d_outR)) & 15) return false;
     int pmax = 0;
     for (int a = 0; a < st.nact; a++) {
         if (!st.act[a].uniform) return false;
         pmax = std::max(pmax, st.act[a].p_end);
     }
-    if (pmax <= 0 || (int64_t)pmax * MC_B > OS_N / 2) return false;  // (a segment at least half new frames)
+    // a block-sliced engine's first segment also carries the blocks whose Q1/Q2 terms its windows reach (their sums come from the column pass)
+    const int ovl = slice ? std::max(pmax, (int)(e->cfg.n_ref / MC_B) + MC_MAX_PREDELAY / MC_B + 2) : pmax;
+    if (pmax <= 0 || (int64_t)ovl * MC_B > OS_N / 2) return false;  // (a segment at least half new frames)
     if (e->res_end > e->t_front * MC_B) return false;
     if (e->epoch_b0 != 0 && e->epoch_b0 + (uint64_t)pmax > e->t_front) return false;
     if (make_taildrop(e, st.ctx.vir, st.ctx.predelay).on) return false;
-    *ovl_blocks = pmax;
+    *ovl_blocks = ovl;
     return true;
 }
 
@@ -1529,6 +1531,8 @@ int ensure_os(mc_engine* e, const Staged& st, int nseg) {
     G.ovl = 0;
     G.n_in = np;
     G.tau0 = 0;
+    G.base = 0;
+    G.wet_end = np;
     G.seg0 = 0;
     for (int i = 0; i < 2; i++) {
         float4* buf = e->d_os_T + seg_el * i;
@@ -1548,25 +1552,33 @@ int ensure_os(mc_engine* e, const Staged& st, int nseg) {
 // the partitioned passes would: the last blocks' delay-line slots, slot gains and histories (k_fwd over the batch's tail), the
 // Q1/Q2 prefix ring, the wet ring where later calls reach, and the last block's segment (its second half opens the next call).
 int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const float* d_in1, const float* d_in2, float* d_outL, float* d_outR,
-           int T, int ovl_blocks, int slot0) {
+           int T, int ovl_blocks, int slot0, bool slice, int first, int count, int halo) {
+    // whole batch: wet frames of blocks [0, T).  Block-sliced: of the slice and the reach-back blocks before it (predelay),
+    // the segments' history read from the batch's own buffers in front of the window
+    const int w0 = slice ? first - halo : 0, wn = slice ? count + halo : T;
     const int64_t ovl = (int64_t)ovl_blocks * MC_B, hop = (int64_t)OS_N - ovl;
     const int hop_blocks = (int)(hop / MC_B);
-    const int nseg = (T + hop_blocks - 1) / hop_blocks;
+    const int nseg = (wn + hop_blocks - 1) / hop_blocks;
     int rc = ensure_os(e, st, nseg);
     if (rc) return rc;
     const BlockParams* d_ptab = st.d_ptab;
-    const hipStream_t main = e->stream, side = e->os_side ? e->os_stream : e->stream;
-    HIP_TRY(hipEventRecord(e->os_ev[0], main));  // the side stream and the work streams start where the engine's stream stands
-    if (side != main) HIP_TRY(hipStreamWaitEvent(side, e->os_ev[0], 0));
-    // state for later calls: delay line, slot gains, input / gain histories of the last blocks (what any later window,
-    // Q8 pass or re-render of a predelay epoch can reach), and the last block's segment as the partitioned passes leave it
-    // (its partition sums from the delay line, one inverse transform: its second half opens the next call)
-    {
+    // (on HIP's special stream handles - MC_STREAM_DEFAULT = hipStreamLegacy, hipStreamPerThread - everything runs in line:
+    // hipStreamWaitEvent on such a handle faults in this runtime)
+    const hipStream_t main = e->stream;
+    const hipStream_t side = (e->os_side && reinterpret_cast<uintptr_t>(main) > 2) ? e->os_stream : main;
+    if (side != main) {  // the side stream starts where the engine's stream stands
+        HIP_TRY(hipEventRecord(e->os_ev[0], main));
+        HIP_TRY(hipStreamWaitEvent(side, e->os_ev[0], 0));
+    }
+    const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
+    DropAhead da;
+    std::memset(&da, 0, sizeof(da));
+    if (!slice) {
+        // state for later calls: delay line, slot gains, input / gain histories of the last blocks (what any later window,
+        // Q8 pass or re-render of a predelay epoch can reach), and the last block's segment as the partitioned passes leave it
+        // (its partition sums from the delay line, one inverse transform: its second half opens the next call)
         const int reach = std::max(round_up(e->Pcap, 16) + 64, (int)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B) + 8);
         const int from = std::max(0, T - reach) & ~(FWD_TILE - 1);
-        const int hist_from = (int)std::max<int64_t>(0, (int64_t)T - (int64_t)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B + 4));
-        DropAhead da;
-        std::memset(&da, 0, sizeof(da));
         hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
                            e->d_fdl, e->ring, slot0, d_ptab, 0, (float4*)nullptr, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
                            e->rc, (int64_t)e->t_front, 0, 0, from, hist_from, from, da);
@@ -1577,8 +1589,14 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         if (!rc) launch_inv(e, mo, b, side);
         e->stream = main;
         if (rc) return rc;
+    } else if (stored.need_b0 < T) {
+        // block-sliced: the tail of the batch that the next call's windows reach back to (delay line, histories, block sums), as k_fwd leaves it
+        const int from = stored.need_b0 & ~(FWD_TILE - 1);
+        hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
+                           e->d_fdl, e->ring, slot0, d_ptab, 0, st.d_sums, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
+                           e->rc, (int64_t)e->t_front, 0, 0, stored.need_b0, hist_from, from, da);
     }
-    const int head = (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
+    const int head = slice ? 0 : (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
     OutArgs oa;
     std::memset(&oa, 0, sizeof(oa));
     oa.in1 = d_in1;
@@ -1595,17 +1613,27 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
     oa.b0 = make_retired(e).b0;
     oa.compat = (int)e->cfg.compat;
     oa.pm = e->pm;
-    oa.out_from = head;
-    oa.out_end = T;
-    oa.out_blk0 = 0;
     oa.blk0 = 0;
-    oa.wet_head = head;
-    oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));
+    if (slice) {  // the slice [first, first + count), nothing else; a sliced engine keeps no wet history
+        oa.out_from = first;
+        oa.out_end = first + count;
+        oa.out_blk0 = first;
+        oa.wet_head = 0;
+        oa.wet_from = 1 << 30;
+    } else {
+        oa.out_from = head;
+        oa.out_end = T;
+        oa.out_blk0 = 0;
+        oa.wet_head = head;
+        oa.wet_from = std::max(0, T - (MC_MAX_PREDELAY / MC_B + 8));
+    }
     OsGeo G;
     G.hop = hop;
     G.ovl = ovl;
     G.n_in = (int64_t)T * MC_B;
     G.tau0 = (int64_t)e->t_front * MC_B;
+    G.base = (int64_t)w0 * MC_B;
+    G.wet_end = (int64_t)(w0 + wn) * MC_B;
     G.seg0 = 0;
     hipLaunchKernelGGL(k_os_cols, dim3(nseg * OS_TPS), dim3(OS_THREADS), 0, main, d_in1, d_in2, (const float*)e->d_xhist, e->xr, G, e->d_os_T,
                        e->cfg.compat ? e->d_os_part : (float4*)nullptr, e->d_tw);
@@ -1620,6 +1648,8 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         ca.parts = e->d_os_part;
         ca.parts_hop = hop_blocks;
         ca.parts_ovl = ovl_blocks;
+        ca.parts_t0 = w0;
+        ca.parts_end = w0 + wn;
         ca.ptab = d_ptab;
         ca.pstride = 0;
         ca.T = T;
@@ -1630,7 +1660,7 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         ca.rc = e->rc;
         ca.tabs0 = (int64_t)st.ctx.t0;
         ca.ctot = e->d_ctot;
-        corr_chunks(&ca, T, 0, T, T);
+        corr_chunks(&ca, T, stored.need_a0, stored.need_a1, stored.need_b0);
         hipLaunchKernelGGL(k_corr_terms, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, side, ca);
         if (ca.nchunks > 1) hipLaunchKernelGGL(k_corr_fix, dim3(ca.nchunks), dim3(CORR_CHUNK), 0, side, ca);
     }
@@ -1640,7 +1670,7 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         if (rc) return rc;
     }
     if (e->ktiming) {
-        e->kev_blocks[e->kev_n] = (uint32_t)T;
+        e->kev_blocks[e->kev_n] = (uint32_t)wn;
         HIP_TRY(hipEventRecord(e->kev[e->kev_n][0], main));
     }
     hipLaunchKernelGGL(k_os_rows, dim3(nseg * OS_ITEMS), dim3(G2B_THREADS), 0, main, e->d_os_T, (const float4*)e->d_os_SP, (const float4*)e->d_os_SP0, nseg);
@@ -1750,8 +1780,9 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
 
     {  // long settled batches: overlap-save segments instead of the three passes below (ossave.hip.h)
         int os_ovl = 0;
-        if (!slice && !lin && !piped && to_wet && os_applies(e, st, T, d_in1, d_in2, d_outL, d_outR, &os_ovl)) {
-            const int rc = run_os(e, st, e->pipe[(e->pipe_head + e->pipe_count) % kPipe], d_in1, d_in2, d_outL, d_outR, T, os_ovl, slot0);
+        const int halo_full = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
+        if (!lin && !piped && to_wet && (!slice || halo == halo_full || wblock == 0) && os_applies(e, st, count, slice, d_in1, d_in2, d_outL, d_outR, &os_ovl)) {
+            const int rc = run_os(e, st, e->pipe[(e->pipe_head + e->pipe_count) % kPipe], d_in1, d_in2, d_outL, d_outR, T, os_ovl, slot0, slice, first, count, halo);
             if (rc) return rc;
             e->pipe_count++;
             e->batch_seq++;

@@ -47,6 +47,8 @@ struct OsGeo {
     int64_t ovl;   // frames of history in front of a segment (multiple of 256, >= taps - 1)
     int64_t n_in;  // frames of the batch (multiple of 256)
     int64_t tau0;  // absolute frame of the batch's frame 0
+    int64_t base;  // frame of the batch at which segment 0's new frames begin (0; a block-sliced engine: where its window begins)
+    int64_t wet_end;  // wet frames of the batch from here on are not produced (n_in; a block-sliced engine: the end of its slice)
     int seg0;      // first segment of this launch
 };
 
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_cols(const float* __restrict_
     os_tile_of((int)blockIdx.x, segl, tile);
     const int n2_0 = tile * OS_TILE;
     const int64_t seg = (int64_t)G.seg0 + segl;
-    const int64_t sbase = seg * G.hop - G.ovl + n2_0;  // batch-relative frame of (n1 = 0, column 0)
+    const int64_t sbase = G.base + seg * G.hop - G.ovl + n2_0;  // batch-relative frame of (n1 = 0, column 0)
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int e = tid + OS_THREADS * it, n1 = e >> 2, q = e & 3;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_os_rows(float4* __restrict__
 // The lane that holds four consecutive wet frames {L = Re, R = Im} of the batch finishes them: Q1/Q2 window sums from the
 // prefix ring (out_window), clamp, dry mix (out_frame), stored at the predelay offset; the frames later calls can reach
 // (blocks < wet_head or >= wet_from) also go to the wet ring.  OutArgs as for k_inv_wet (lin, drop unused: null).
-// Bounds: wet frames i0 in [seg hop, min((seg + 1) hop, n_in)); output frames tested against [out_from, out_end) blocks;
+// Bounds: wet frames i0 in [base + seg hop, min(base + (seg + 1) hop, wet_end)), wet_end <= n_in; output frames tested against [out_from, out_end) blocks;
 // ring indices masked.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict__ Tbuf, OsGeo G, float* __restrict__ wet, int wr,
@@ -397,13 +399,13 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict_
     for (int it = 0; it < 2; it++) {
         const int e = tid + OS_THREADS * it, n1 = e >> 2, q = e & 3;
         const int64_t n = (int64_t)OS_N2 * n1 + n2_0 + 4 * q;
-        const int64_t i0 = seg * G.hop - G.ovl + n;  // wet frame of the batch
-        if (n < G.ovl || i0 >= G.n_in) continue;
+        const int64_t i0 = G.base + seg * G.hop - G.ovl + n;  // wet frame of the batch
+        if (n < G.ovl || i0 >= G.wet_end) continue;
         const float2* zz = s_mem + (4 * q) * OS_WSTR + n1;
         const float2 z0 = zz[0], z1 = zz[OS_WSTR], z2 = zz[2 * OS_WSTR], z3 = zz[3 * OS_WSTR];
         const float4 wl4 = make_float4(z0.x, z1.x, z2.x, z3.x), wr4 = make_float4(z0.y, z1.y, z2.y, z3.y);
         const int t = (int)(i0 >> 8);
-        if (t < oa.wet_head || t >= oa.wet_from) {
+        if (i0 >= 0 && (t < oa.wet_head || t >= oa.wet_from)) {
             const size_t at = (size_t)((G.tau0 + i0) & (int64_t)(wr - 1));
             *reinterpret_cast<float4*>(wet + at) = wl4;
             *reinterpret_cast<float4*>(wet + wr + at) = wr4;

@@ -1936,6 +1936,75 @@ def test_overlap_save_form_keeps_out_of_the_q8_regime_and_of_retired_epochs(gpu_
         assert d <= 1e-6, f"batch {k}: {d:.3e}"
 
 
+@pytest.mark.parametrize("pd", [0, 1024, 301])
+def test_overlap_save_form_of_block_slices(oracle_mod, gpu_lib, monkeypatch, pd):
+    """Block-sliced engines (one per GPU, the same batch on all, no collective) take the overlap-save form for their slices too:
+    the segments of a slice read their history from the batch's own buffers in front of the slice (rank 0: from the input-history
+    ring, which the forward transforms of the previous batch's tail filled), the first segment also carries the blocks whose
+    Q1/Q2 terms the slice's windows reach.  Two virtual ranks on one card against an unsliced engine running the partitioned
+    passes (MCCONV_OS=0), and the second batch's middle against the range oracle."""
+    import torch
+
+    from cuda_audio_amd.sharded import slice_bounds
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, taps, world = 131072, (88200, 80000), 2
+    T = 2 * 13000
+    nbat = 3
+    x = make_input(nbat * T * 256)
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
+    p0, p1 = dict(BASE, predelay=pd, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9, predelay=pd)
+    dx = torch.from_numpy(x).cuda()
+
+    def mk(os_on, max_batch):
+        monkeypatch.setenv("MCCONV_OS", "1" if os_on else "0")
+        c = _conv(fftSize=n_ref, max_batch=max_batch)
+        for i, ir in enumerate(irs):
+            c.prepare(i, ir)
+        apply_params(c, p0, p1, False)
+        c.use_torch_stream()
+        c.enable_kernel_timing(True)
+        return c
+
+    whole = mk(False, T)
+    ranks = [mk(True, T) for _ in range(world)]
+    ref = torch.zeros(2, nbat * T * 256, device="cuda")
+    got = torch.zeros(2, nbat * T * 256, device="cuda")
+    levels = []
+    for k in range(nbat):
+        sl = slice(k * T * 256, (k + 1) * T * 256)
+        xin = dx[:, sl].contiguous()
+        o = torch.zeros(2, T * 256, device="cuda")
+        whole.process_device(xin[0].data_ptr(), xin[1].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), T)
+        ref[:, sl] = o
+        for r, c in enumerate(ranks):
+            first, count = slice_bounds(T, world, r, 1)
+            oo = torch.zeros(2, count * 256, device="cuda")
+            c.process_slice_device(xin[0].data_ptr(), xin[1].data_ptr(), oo[0].data_ptr(), oo[1].data_ptr(), T, first, count)
+            torch.cuda.synchronize()
+            levels.append(c.kernel_stats()["fast_levels"])
+            got[:, (k * T + first) * 256:(k * T + first + count) * 256] = oo
+    torch.cuda.synchronize()
+    st = [c.os_stats()["batches"] for c in ranks]
+    for c in ranks + [whole]:
+        c.close()
+    ref, got = ref.cpu().numpy(), got.cpu().numpy()
+    assert 253 not in levels[:2] and levels[2:] == [253] * (2 * nbat - 2), levels  # (the first batch's window holds the cold-start ramp)
+    assert st == [nbat - 1] * world, st
+    for k in range(nbat):
+        d = rms(got[:, k * T * 256:(k + 1) * T * 256] - ref[:, k * T * 256:(k + 1) * T * 256])
+        assert d <= 1e-6, f"batch {k}: {d:.3e} from the unsliced partitioned passes"
+    b0, n = T + T // 2 - 60, 120  # across the slice boundary of the second batch
+    u = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+    apply_params(u, p0, p1, True)
+    want = u.range(x[0], x[1], b0, n)
+    u.close()
+    err = rms(got[:, b0 * 256:(b0 + n) * 256] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
 def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     """k_g2_mac's workgroups stride over the (bin, chunk) items (default: one workgroup per item).  Any grid - one
     workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor of the items, exactly the items,
