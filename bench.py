@@ -97,6 +97,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--pipeline", action="store_true",
                     help="mc_config.pipeline: post stage of batch k on a second stream under the MAC of batch k + 1")
+    ap.add_argument("--no-direct-mac", action="store_true", help="N > 1: skip the third curve (partition shards with the literal resident MAC)")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -825,8 +826,23 @@ def main():
         return res
 
     # ------------------------------------------------------------------ multi GPU, layout 1: output blocks sliced
-    def run_blocks():
+    def sliced_preferred():
+        """Output blocks per rank of a block-sliced step: whole segments of the overlap-save form (a slice's segments are 16384 -
+        max(P16, n_ref / 256 + 34) blocks: the first one also carries the blocks whose Q1/Q2 terms the slice's windows reach) minus
+        the reach-back blocks of the predelay; the engine's own preference where that form does not apply."""
         Tb = preferred()
+        if a.blocks > 0 or a.precision != "fp32" or os.environ.get("MCCONV_OS") == "0" or a.pipeline:
+            return Tb
+        p16 = -(-P // 16) * 16
+        hop = 16384 - max(p16, a.fft_size // BLOCK + 8192 // BLOCK + 2)
+        halo = -(-a.predelay // BLOCK) + 1
+        k = a.max_blocks // hop
+        if min(a.taps, a.fft_size - 1024) + 255 + a.predelay > a.fft_size or k < 1 or k * hop - halo < 12288:
+            return Tb  # (Q8 regime, or a limit below one segment: the partitioned passes)
+        return k * hop - halo
+
+    def run_blocks():
+        Tb = sliced_preferred()
         T = Tb * shard_world  # weak scaling: every rank finishes Tb output blocks of a batch of N x Tb
         first, count = slice_bounds(T, shard_world, rank)
         pipelined = a.pipeline and a.precision == "fp32"
@@ -921,11 +937,18 @@ def main():
         return res
 
     # ------------------------------------------------------------------ multi GPU, layout 2: IR partitions sharded + RCCL sum
-    def run_partitions():
+    def run_partitions(direct=False):
+        # direct: the sum over partitions as the literal resident MAC (MCCONV_FFT2=0, read when an engine is created) - the one
+        # form whose per-rank work is P / N partitions per block, i.e. the strong-scaling curve the north star describes
         pb, pe = shard_bounds(P, shard_world, rank)
         if pe <= pb:
             raise SystemExit("empty shard; use fewer ranks")
+        keep_env = os.environ.get("MCCONV_FFT2")
+        if direct:
+            os.environ["MCCONV_FFT2"] = "0"
         T = preferred(*shard_bounds(P, shard_world, 0))  # the same batch length on every rank: rank 0's shard decides
+        if direct:
+            T = min(T, 32768) // shard_world * shard_world  # (the MAC costs P / N partitions per block: shorter steps keep the run short)
         coll = a.collective
         if coll == "reduce_scatter" and T % shard_world:
             coll = "reduce"  # (the slices of a reduce-scatter are equal runs of whole blocks)
@@ -934,6 +957,11 @@ def main():
         Ts = T // shard_world if rs else T          # blocks this rank finishes
         first = rank * Ts if rs else 0
         eng = Pairs(a, local, npairs, T, part_begin=pb, part_end=pe)
+        if direct:
+            if keep_env is None:
+                os.environ.pop("MCCONV_FFT2", None)
+            else:
+                os.environ["MCCONV_FFT2"] = keep_env
         xs, d_in = make_inputs(T)
         d_out = [torch.zeros(2, Ts * BLOCK, device=dev) for _ in range(npairs)]
         # the partial wet blocks of all pairs of a rank: [pair][channel][T * 256]
@@ -1005,11 +1033,12 @@ def main():
             while pending:
                 retire()
 
-        dt, npre = timed(step, drain, a.steps, a.warmup, a.prewarm_ms)
+        dt, npre = timed(step, drain, max(2, a.steps // 4) if direct else a.steps, min(a.warmup, 2) if direct else a.warmup, 0.0 if direct else a.prewarm_ms)
+        nsteps = max(2, a.steps // 4) if direct else a.steps
         lv = None
         n = shard_world
         sent = int(npairs * 2 * T * BLOCK * 4 * ((n - 1) / n if rs else (1.0 if root_only_ else 2.0 * (n - 1) / n)))
-        res = {"T": T, "dt": dt, "rtf": a.steps * T * BLOCK / FS / dt, "partitions_per_rank": pe - pb, "prewarm_steps": npre,
+        res = {"T": T, "dt": dt, "steps": nsteps, "rtf": nsteps * T * BLOCK / FS / dt, "partitions_per_rank": pe - pb, "prewarm_steps": npre,
                "collective": coll, "blocks_finished_per_rank": Ts, "reduce_bytes_per_step": int(npairs * 2 * T * BLOCK * 4),
                "reduce_bytes_per_rank_per_step": sent}
         # what the first hardware run should explain by itself: the kernels alone, the collective alone, and which one binds
@@ -1031,7 +1060,7 @@ def main():
                 e.reset()
             eng[0].enable_kernel_timing(True)
             kept = []
-            nchk = 3
+            nchk = 2 if direct else 3
             for k in range(nchk):
                 step(k)
             drain()
@@ -1205,6 +1234,7 @@ def main():
     else:
         rb = run_blocks() if a.layouts in ("both", "blocks") else None
         rp = run_partitions() if a.layouts in ("both", "partitions") else None
+        rpd = run_partitions(direct=True) if (a.layouts in ("both", "partitions") and a.precision == "fp32" and not a.no_direct_mac) else None
         main_r = rb if rb is not None else rp
         by_blocks = rb is not None
         ex = "RCCL" if a.backend == "nccl" else "gloo (rehearsal)"
@@ -1249,6 +1279,18 @@ def main():
                 line["north_star_layout"] = ns
             else:
                 line["sharded_check"] = rp.get("sharded_check")
+        if rpd is not None:
+            nd = {"value": round(rpd["rtf"], 2), "unit": "x realtime", "ms_per_step": round(rpd["dt"] / rpd["steps"] * 1e3, 4), "steps": rpd["steps"],
+                  "scaling": "strong", "blocks_per_step": rpd["T"], "partitions_per_rank": rpd["partitions_per_rank"],
+                  "sum_over_partitions": rpd["sum_over_partitions"], "collective": rpd["collective"],
+                  "reduce_bytes_per_rank_per_step": rpd["reduce_bytes_per_rank_per_step"],
+                  "note": "the same partition shards + reduce-scatter with the sum over partitions as the literal resident MAC (MCCONV_FFT2=0): "
+                          "the one form whose per-rank work falls as P / N - the strong-scaling curve BASELINE's north star describes. Far "
+                          "slower in absolute terms than the transform forms (every block re-reads its shard of the IR spectra)."}
+            for k in ("kernels_only_ms_per_step", "collective_only_ms_per_step", "collective_GBps_per_rank", "link_bound", "sharded_check"):
+                if k in rpd:
+                    nd[k] = rpd[k]
+            line["north_star_layout_direct_mac"] = nd
     if rank == 0:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if sharded:
