@@ -26,6 +26,16 @@
 #include "ossave.hip.h"
 #include "singlefft.hip.h"
 
+// Environment switches.  The default library reads ten - MCCONV_FORM, _OS, _FFT2, _FFT2_FUSED, _FFA_LEVELS (which form sums the
+// partitions), _TD_FFT (Q8 cut terms in the time domain), _NO_PARK, _PARK_MS, _NO_SPIN, _BAR_IO (the JACK path's waiting and I/O) -
+// all of which select paths a caller can also reach through mc_config or that the tests compare bit for bit.  Every other switch
+// of rounds 1-3 selects a measured-and-lost alternative or a measurement and exists only under -DMCCONV_LAB (scripts/build_variant.sh).
+#ifdef MCCONV_LAB
+#define LAB_ENV(name) std::getenv(name)
+#else
+#define LAB_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -514,7 +524,7 @@ void invalidate_derived(IrEntry& ir) {
 constexpr int kTailSpan = 48;
 int ensure_htail(mc_engine* e, const IrEntry* irc) {
     IrEntry& ir = *const_cast<IrEntry*>(irc);
-    static const bool off = std::getenv("MCCONV_HTAIL") && std::atoi(std::getenv("MCCONV_HTAIL")) == 0;
+    static const bool off = LAB_ENV("MCCONV_HTAIL") && std::atoi(LAB_ENV("MCCONV_HTAIL")) == 0;
     if (ir.tail_valid || !ir.d_H || off) return MC_OK;
     if (!ir.d_Htail) HIP_TRY(hipMalloc(&ir.d_Htail, sizeof(float4) * (size_t)kTailSpan * MC_NB));
     ir.tail_p0 = std::max(0, ir.P - kTailSpan);
@@ -1147,18 +1157,21 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                         fprintf(stderr, "  G2[%d] in1 [%p, %p) in2 [%p, %p)\n", a, (void*)vv.h0[a], (void*)(vv.h0[a] + (size_t)2 * 257 * G2_N),
                                 (void*)vv.h1[a], (void*)(vv.h1[a] + (size_t)2 * 257 * G2_N));
                 }
+#ifdef MCCONV_LAB  // the measured alternatives of k_g2_mac (lab_kernels.hip.h)
                 if (e->g2_duo && !e->g2_wide && nch >= e->g2_duo_minch && e->g2_grid == (1 << 30)) {
                     // the lockstep form: persistent, two workers (the halves of a workgroup) per CU; the Q1/Q2 terms do not ride
                     // along (a rider would need a CU of its own: the launches of their own follow, as for every long batch)
                     const int grid = std::max(8, std::min(e->g2_duo_grid, 256) & ~7);
-                    static const int solo = std::getenv("MCCONV_G2_DUO_SOLO") ? std::atoi(std::getenv("MCCONV_G2_DUO_SOLO")) : 0;  // (measurement: one group works alone)
+                    static const int solo = LAB_ENV("MCCONV_G2_DUO_SOLO") ? std::atoi(LAB_ENV("MCCONV_G2_DUO_SOLO")) : 0;  // (measurement: one group works alone)
                     const int wpl = (grid >> 3) * (solo ? 1 : 2), nxq = (MC_NB * nch) >> 3;
                     hipLaunchKernelGGL(k_g2_duo, dim3(grid), dim3(G2D_THREADS), 0, e->stream, e->d_fdl, e->ring, slot0, T, chunk_t, pmax, vv,
                                        e->d_Yc, e->Tcap, MC_NB * nch, (nxq + wpl - 1) / wpl, solo);
                 } else if (e->g2_wide)  // the one-workgroup-per-CU form (MCCONV_G2_WIDE=1)
                     hipLaunchKernelGGL(k_g2_mac_wide, dim3(std::min(MC_NB * nch, e->g2_grid)), dim3(G2_THREADS), 0, e->stream, e->d_fdl,
                                        e->ring, slot0, T, chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch);
-                else {
+                else
+#endif
+                {
                     CorrArgs ca;
                     std::memset(&ca, 0, sizeof(ca));
                     if (ride && ride->nchunks > 0) {
@@ -1166,7 +1179,7 @@ int launch_mac_batch(mc_engine* e, const ActiveVoice* act, int nact, bool per_sl
                         mo->corr_done = true;
                     }
                     const int main_grid = std::min(MC_NB * nch, e->g2_grid);
-                    static const int dyn_lds = std::getenv("MCCONV_G2_DYNLDS") ? std::atoi(std::getenv("MCCONV_G2_DYNLDS")) : 0;  // (measurement: extra LDS per workgroup, > 22 KB leaves one workgroup per CU)
+                    static const int dyn_lds = LAB_ENV("MCCONV_G2_DYNLDS") ? std::atoi(LAB_ENV("MCCONV_G2_DYNLDS")) : 0;  // (measurement: extra LDS per workgroup, > 22 KB leaves one workgroup per CU)
                     hipLaunchKernelGGL(k_g2_mac, dim3(main_grid + ca.nchunks), dim3(G2B_THREADS), dyn_lds, e->stream, e->d_fdl, e->ring, slot0, T,
                                        chunk_t, pmax, vv, e->d_Yc, e->Tcap, MC_NB * nch, ca, main_grid);
                 }
@@ -2997,8 +3010,8 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     // (pipelined: the forward stage of batch k + 1 writes histories while the post stage of batch k still reads them)
     e->rc = (int)next_pow2(cfg->n_ref / MC_B + (uint64_t)e->Tmax * (e->pipelined ? 2 : 1) + 64);
     e->stream_threshold = cfg->stream_threshold ? (int)cfg->stream_threshold : 48;  // measured crossover (scripts/sweep_T.sh)
-    if (const char* nc = std::getenv("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
-    if (const char* nt = std::getenv("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
+    if (const char* nc = LAB_ENV("MCCONV_NCHUNK")) e->nchunk = std::max(1, std::min(64, std::atoi(nc)));
+    if (const char* nt = LAB_ENV("MCCONV_STREAM_NT")) e->stream_nt = std::atoi(nt) == 512 ? 512 : 256;
     {
         const uint32_t period = cfg->period ? cfg->period : MC_BLOCK;
         if (period != 256 && period != 512 && period != 1024) {
@@ -3126,7 +3139,7 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     e->h_exited = e->h_flag + 32;
     e->hd_exited = e->hd_flag + 32;
     if (std::getenv("MCCONV_NO_PARK")) e->park = false;
-    if (const char* ho = std::getenv("MCCONV_HOST_OUT_DIRECT")) e->host_out_direct = std::atoi(ho) != 0;
+    if (const char* ho = LAB_ENV("MCCONV_HOST_OUT_DIRECT")) e->host_out_direct = std::atoi(ho) != 0;
     {
         int large_bar = 0;
         const char* bi = std::getenv("MCCONV_BAR_IO");
@@ -3143,12 +3156,12 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipMalloc(&e->d_done_ctr, sizeof(unsigned)));
     ENG_TRY(hipMemset(e->d_done_ctr, 0, sizeof(unsigned)));
     if (std::getenv("MCCONV_NO_SPIN")) e->spin_wait = false;
-    if (e->bar_io && e->spin_wait && !(std::getenv("MCCONV_TAGGED_IO") && std::atoi(std::getenv("MCCONV_TAGGED_IO")) == 0)) {
+    if (e->bar_io && e->spin_wait && !(LAB_ENV("MCCONV_TAGGED_IO") && std::atoi(LAB_ENV("MCCONV_TAGGED_IO")) == 0)) {
         ENG_TRY(hipHostMalloc(&e->h_gran, sizeof(unsigned long long) * 2 * 4 * MC_B, hipHostMallocMapped));  // (room for a 1024-frame period)
         ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_gran, e->h_gran, 0));
         std::memset(e->h_gran, 0, sizeof(unsigned long long) * 2 * 4 * MC_B);
         e->tio = true;
-        e->tio_long = std::getenv("MCCONV_TAGGED_IO") && std::atoi(std::getenv("MCCONV_TAGGED_IO")) == 2;
+        e->tio_long = LAB_ENV("MCCONV_TAGGED_IO") && std::atoi(LAB_ENV("MCCONV_TAGGED_IO")) == 2;
     }
     for (int i = 0; i < kStageBufs; i++) {
         ENG_TRY(hipHostMalloc(&e->h_ptab[i], sizeof(BlockParams) * (size_t)e->Tmax, hipHostMallocDefault));
@@ -3157,12 +3170,12 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     ENG_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) ENG_TRY(hipMalloc(&e->d_part_jack[i], sizeof(float4) * (size_t)MC_NB * e->nchunk * MC_MAXV));
     for (int i = 0; i < 2; i++) ENG_TRY(hipMalloc(&e->d_drop[i], sizeof(float) * 2 * 4 * MC_B));
-    if (std::getenv("MCCONV_NO_SPECULATE")) e->speculate = false;
+    if (LAB_ENV("MCCONV_NO_SPECULATE")) e->speculate = false;
     if (const char* f2 = std::getenv("MCCONV_FFT2")) e->fft2 = std::atoi(f2) != 0;
     if (const char* g2 = std::getenv("MCCONV_FFT2_FUSED")) e->fft2_fused = std::atoi(g2) != 0;
     {
         int cus = 0;
-        if (const char* gw = std::getenv("MCCONV_G2_WIDE")) e->g2_wide = std::atoi(gw) != 0;
+        if (const char* gw = LAB_ENV("MCCONV_G2_WIDE")) e->g2_wide = std::atoi(gw) != 0;
         // k_g2_mac: one workgroup per (bin, chunk) item - the dispatcher keeps two resident per CU and hands a CU its next
         // one the moment a slot frees (measured against 512 persistent workgroups striding over 1280 items: 98 vs 108 us).
         // The one-workgroup-per-CU form is persistent (one per CU, look-ahead into its next item).
@@ -3170,27 +3183,27 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
         if (e->g2_wide) e->g2_grid = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) ? (cus & ~7) : 256;
     }
     // (any grid >= 1 is correct: a workgroup strides over the items; multiples of 8 keep a bin's chunks on one XCD)
-    if (const char* gg = std::getenv("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
-    if (const char* gd = std::getenv("MCCONV_G2_DUO")) e->g2_duo = std::atoi(gd) != 0;
-    if (const char* gd = std::getenv("MCCONV_G2_DUO_MINCH")) e->g2_duo_minch = std::max(1, std::atoi(gd));
+    if (const char* gg = LAB_ENV("MCCONV_G2_GRID")) e->g2_grid = std::max(1, std::atoi(gg));
+    if (const char* gd = LAB_ENV("MCCONV_G2_DUO")) e->g2_duo = std::atoi(gd) != 0;
+    if (const char* gd = LAB_ENV("MCCONV_G2_DUO_MINCH")) e->g2_duo_minch = std::max(1, std::atoi(gd));
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus >= 8) e->g2_duo_grid = std::min(cus & ~7, 256);
     }
-    if (const char* gd = std::getenv("MCCONV_G2_DUO_GRID")) e->g2_duo_grid = std::max(8, std::atoi(gd));
-    if (std::getenv("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
-    if (const char* cr = std::getenv("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
-    if (const char* tm = std::getenv("MCCONV_FFT2_WORK")) e->fft2_work = std::max<int64_t>(1, std::atoll(tm));
-    if (const char* gm = std::getenv("MCCONV_G2_PMIN")) e->g2_pmin = std::max(16, std::atoi(gm));
-    if (const char* gp = std::getenv("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
-    if (const char* fo = std::getenv("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
-    if (const char* fo = std::getenv("MCCONV_FUSE_DROP")) e->fuse_drop = std::atoi(fo) != 0;
-    if (const char* fo = std::getenv("MCCONV_DROP_AHEAD")) e->drop_ahead = std::atoi(fo) != 0;
-    if (const char* fo = std::getenv("MCCONV_CARRY_DROP")) e->carry_drop = std::atoi(fo) != 0;
-    if (const char* iw = std::getenv("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
+    if (const char* gd = LAB_ENV("MCCONV_G2_DUO_GRID")) e->g2_duo_grid = std::max(8, std::atoi(gd));
+    if (LAB_ENV("MCCONV_DEBUG_ADDR")) e->debug_addr = true;
+    if (const char* cr = LAB_ENV("MCCONV_CORR_RIDE")) e->corr_ride = std::atoi(cr) != 0;
+    if (const char* tm = LAB_ENV("MCCONV_FFT2_WORK")) e->fft2_work = std::max<int64_t>(1, std::atoll(tm));
+    if (const char* gm = LAB_ENV("MCCONV_G2_PMIN")) e->g2_pmin = std::max(16, std::atoi(gm));
+    if (const char* gp = LAB_ENV("MCCONV_G2_PMAX")) e->g2_pmax = std::max(256, std::min(G2_N / 2 + 2048, std::atoi(gp)));
+    if (const char* fo = LAB_ENV("MCCONV_FUSE_OUT")) e->fuse_out = std::atoi(fo) != 0;
+    if (const char* fo = LAB_ENV("MCCONV_FUSE_DROP")) e->fuse_drop = std::atoi(fo) != 0;
+    if (const char* fo = LAB_ENV("MCCONV_DROP_AHEAD")) e->drop_ahead = std::atoi(fo) != 0;
+    if (const char* fo = LAB_ENV("MCCONV_CARRY_DROP")) e->carry_drop = std::atoi(fo) != 0;
+    if (const char* iw = LAB_ENV("MCCONV_INV_WET")) e->inv_to_wet = std::atoi(iw) != 0;
     if (const char* os = std::getenv("MCCONV_OS")) e->os_on = std::atoi(os) != 0;
-    if (const char* os = std::getenv("MCCONV_OS_SIDE")) e->os_side = std::atoi(os) != 0;
-    if (const char* os = std::getenv("MCCONV_OS_MIN")) e->os_min_blocks = std::max(1, std::atoi(os));
+    if (const char* os = LAB_ENV("MCCONV_OS_SIDE")) e->os_side = std::atoi(os) != 0;
+    if (const char* os = LAB_ENV("MCCONV_OS_MIN")) e->os_min_blocks = std::max(1, std::atoi(os));
     if (const char* fl = std::getenv("MCCONV_FFA_LEVELS")) e->ffa_levels = std::max(0, std::min(3, std::atoi(fl)));
     {
         std::vector<float2> tw;
@@ -3706,6 +3719,16 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
     if (which == 10) {  // batches by the form their partition sums took {fused, split second-level transform, resident MAC}: no stream access
         if (off + bytes > sizeof(e->n_mac_form)) return fail(MC_ERR_ARG, "read beyond the counters");
         std::memcpy(dst, reinterpret_cast<const char*>(e->n_mac_form) + off, bytes);
+        return MC_OK;
+    }
+    if (which == 15) {  // 1 = built with -DMCCONV_LAB (the measurement switches and the alternative kernels exist): no stream access
+#ifdef MCCONV_LAB
+        const uint64_t lab = 1;
+#else
+        const uint64_t lab = 0;
+#endif
+        if (off + bytes > sizeof(lab)) return fail(MC_ERR_ARG, "read beyond the word");
+        std::memcpy(dst, reinterpret_cast<const char*>(&lab) + off, bytes);
         return MC_OK;
     }
     if (which == 11) {  // overlap-save form: {batches that took it, spectra builds}: no stream access

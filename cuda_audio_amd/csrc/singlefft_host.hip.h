@@ -41,7 +41,7 @@ inline int sf_create(mc_engine* e) {
     s->M = (int)(N / FFT_N);
     s->AT = std::max(1, std::min(8, 2048 / s->M));
     s->lds_bytes = sizeof(float2) * (size_t)(2 * s->AT * s->M + s->M / 2);
-    s->stockham = std::getenv("MCCONV_SF_STOCKHAM") != nullptr;  // (tests: the LDS transform of the long sizes at a short one)
+    s->stockham = LAB_ENV("MCCONV_SF_STOCKHAM") != nullptr;  // (tests: the LDS transform of the long sizes at a short one)
     HIP_TRY(hipMalloc(&s->d_live, sizeof(float2) * 4 * (size_t)(N / 2)));
     HIP_TRY(hipMalloc(&s->d_W, sizeof(float2) * N));
     HIP_TRY(hipMalloc(&s->d_T, sizeof(float2) * N));

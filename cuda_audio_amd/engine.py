@@ -280,6 +280,13 @@ class Convolution:
         check(self._L.mc_debug_read(self._h, 11, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
         return dict(batches=int(a[0]), spectra_builds=int(a[1]))
 
+    def lab_build(self):
+        """True when the loaded library was built with -DMCCONV_LAB: the measurement switches of rounds 1-3 and the alternative
+        kernels exist only there (mc_debug_read item 15)."""
+        a = np.zeros(1, np.uint64)
+        check(self._L.mc_debug_read(self._h, 15, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return bool(a[0])
+
     def param_generation(self, published=False):
         """Generation number of the parameter pair the last process call ran on (published=True: of the pair
         published last).  Every mc_set_params / mc_handle_cc publishes a new pair (csrc/params_handoff.h)."""

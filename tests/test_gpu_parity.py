@@ -741,9 +741,12 @@ def test_q8_with_crossfading_irs_and_longer_periods(oracle_mod, gpu_lib, period,
         got[:, s] = c.process(x[0, s], x[1, s])
         k += n
     stats = c.drop_stats()
+    lab = c.lab_build()
     c.close()
     err = rms(got - want)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+    if form == "no_drop_ahead" and not lab:
+        return  # (MCCONV_DROP_AHEAD exists in the lab build only: here the run repeated the default form)
     # the form under test is the form that ran
     if os.environ.get("MCCONV_TD_FFT") == "0" and form != "tiles":
         form = "tiles"  # (the whole suite under that switch)
