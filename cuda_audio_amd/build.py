@@ -23,6 +23,24 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+# the multi-GPU driver (include/mcconv_group.h): links the engine library and RCCL
+GROUP_SRC = os.path.join(HERE, "csrc", "mcgroup.hip")
+GROUP_OUT = os.path.join(HERE, "libmcconv_rccl.so")
+GROUP_DEPS = [GROUP_SRC, os.path.join(os.path.dirname(HERE), "include", "mcconv_group.h"), os.path.join(os.path.dirname(HERE), "include", "mcconv.h")]
+
+
+def build_group(force=False, verbose=False):
+    if not force and os.path.exists(GROUP_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(GROUP_OUT) for d in GROUP_DEPS + [OUT]):
+        return GROUP_OUT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [hipcc()] + FLAGS + ["-o", GROUP_OUT, GROUP_SRC, "-L" + HERE, "-lmcconv", "-L" + os.path.join(rocm, "lib"), "-lrccl",
+                               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return GROUP_OUT
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -42,4 +60,6 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_group(force="--force" in sys.argv, verbose=True)
     print(OUT)
+    print(GROUP_OUT)

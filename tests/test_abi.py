@@ -9,8 +9,8 @@ from cuda_audio_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mcconv.h")).read()
+def _declared(header="mcconv.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", src)))
 
@@ -22,6 +22,22 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_group_library_exports_every_declared_symbol():
+    """libmcconv_rccl.so (the native multi-GPU driver, include/mcconv_group.h) loads - it links libmcconv.so and librccl.so -
+    and exports what its header declares; argument errors come back without a GPU."""
+    from cuda_audio_amd import group
+
+    L = group.load()
+    declared = _declared("mcconv_group.h")
+    assert len(declared) == 10
+    assert not [s for s in declared if not hasattr(L, s)]
+    assert sorted(group.SYMBOLS) == declared
+    h = C.c_void_p()
+    assert L.mc_group_create(None, None, 0, C.byref(h)) == -1
+    assert b"bad argument" in L.mc_group_last_error()
+    assert L.mc_group_size(None) == 0 and L.mc_group_exchange(None) == b"none"
 
 
 def test_struct_layouts_and_defaults():

@@ -2008,6 +2008,63 @@ def test_overlap_save_form_of_block_slices(oracle_mod, gpu_lib, monkeypatch, pd)
     assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
 
 
+@pytest.mark.parametrize("ranks", [1, 2, 4, -1], ids=["one", "two_virtual", "four_virtual", "one_through_rccl"])
+def test_native_group_driver(oracle_mod, gpu_lib, ranks):
+    """include/mcconv_group.h (libmcconv_rccl.so): IR partitions sharded over the listed devices by a native driver - one host
+    thread per device, the partial wet blocks summed by ncclReduceScatter on the engines' streams, every rank finishing its run of
+    blocks.  On a one-GPU box: a group of ONE device runs RCCL-free and must equal the plain engine bit for bit; listing device 0
+    two / four times makes virtual ranks on one card (RCCL refuses duplicate devices in a communicator: a sum kernel stands in
+    for the collective, mc_group_exchange says so) - partition runs, per-rank threads, slice finishes and host copies are the
+    real ones; and one device sent through partial -> ncclReduceScatter on a communicator of one -> slice finish runs the RCCL
+    calls themselves (more than one rank of them has never run: no multi-GPU node has been available).  Batches that split evenly (reduce-scatter shape) and one that does not (reduce to rank 0), against the plain engine
+    and the oracle."""
+    from cuda_audio_amd.group import ConvolutionGroup
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, taps = 131072, (88200, 80000)
+    sizes = [512, 2048, 1023, 2048]
+    nb = sum(sizes)
+    x = make_input(nb * 256)
+    irs = [make_ir(t, seed=5678 + 2 * j, norm=0.02) for j, t in enumerate(taps)]
+    p0, p1 = dict(BASE, predelay=300, wet=0.7, panWet=0.25), dict(BASE, select=1, level=0.9)
+    solo = ranks < 0
+    ranks = abs(ranks)
+    c = _conv(fftSize=n_ref, max_batch=max(sizes))
+    g = ConvolutionGroup(n_ref, [0] * ranks, max_batch=max(sizes), solo_exchange=solo)
+    assert g.size() == ranks and g.exchange() == ("rccl" if solo else "none" if ranks == 1 else "device-sum")
+    bounds = [g.shard(r) for r in range(ranks)]
+    assert bounds[0][0] == 0 and all(bounds[r][1] == bounds[r + 1][0] for r in range(ranks - 1)) and bounds[-1][1] >= 345
+    for i, ir in enumerate(irs):
+        c.prepare(i, ir)
+        g.prepare(i, ir)
+    apply_params(c, p0, p1, False)
+    for half, p in ((0, p0), (1, p1)):
+        g.set_params(half, **p)
+    ref = np.zeros((2, nb * 256), np.float32)
+    got = np.zeros((2, nb * 256), np.float32)
+    o = 0
+    for n in sizes:
+        s = slice(o * 256, (o + n) * 256)
+        ref[:, s] = c.process(x[0, s], x[1, s])
+        got[:, s] = g.process(x[0, s], x[1, s])
+        o += n
+    c.close()
+    g.close()
+    if ranks == 1:  # (one rank sums all partitions in the plain engine's order: the same bits, with or without the exchange)
+        assert np.array_equal(got, ref)
+    else:
+        assert 0 < rms(got - ref) <= 1e-6, rms(got - ref)
+    nchk = 1200
+    u = oracle_mod.Upols(n_ref, True)
+    for i, ir in enumerate(irs):
+        u.prepare(i, ir)
+    apply_params(u, p0, p1, True)
+    want = u.process(x[0, : nchk * 256], x[1, : nchk * 256])
+    u.close()
+    err = rms(got[:, : nchk * 256] - want)
+    assert err <= RMS_TOL, f"rms {err:.3e} (signal {rms(want):.3e})"
+
+
 def test_fused_second_level_kernel_for_any_grid(gpu_lib, monkeypatch):
     """k_g2_mac's workgroups stride over the (bin, chunk) items (default: one workgroup per item).  Any grid - one
     workgroup, fewer / more than the CUs, not a multiple of the 8 XCDs, not a divisor of the items, exactly the items,
