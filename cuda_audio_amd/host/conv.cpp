@@ -4,7 +4,18 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../include/mcconv.h"
+#include "../../include/mcconv_group.h"
+
+// the multi-device driver is optional at link time (libmcconv_rccl.so): the single-device host and the stub host do without it
+extern "C" {
+int mc_group_create(const mc_config*, const int32_t*, uint32_t, mc_group**) __attribute__((weak));
+void mc_group_destroy(mc_group*) __attribute__((weak));
+mc_engine* mc_group_engine(mc_group*, uint32_t) __attribute__((weak));
+int mc_group_load_ir(mc_group*, uint64_t, const float*, uint64_t, uint64_t) __attribute__((weak));
+int mc_group_set_params(mc_group*, int, const mc_cc_value*) __attribute__((weak));
+int mc_group_process_batch(mc_group*, const float*, const float*, float*, float*, uint64_t) __attribute__((weak));
+const char* mc_group_last_error(void) __attribute__((weak));
+}
 
 namespace {
 void check(int rc, const char* what) {
@@ -25,8 +36,33 @@ Convolution::Convolution(const std::string& name, size_t fftSize)
     check(mc_create(&cfg, &_engine), "mc_create");
 }
 
+Convolution::Convolution(const std::string& name, size_t fftSize, const std::vector<int>& devices, size_t maxBatch)
+    : JackClient(name), capture{nullptr, nullptr}, playback{nullptr, nullptr}, _fftSize(fftSize), _maxBatch(maxBatch) {
+    mc_config cfg;
+    mc_default_config(&cfg);
+    cfg.n_ref = fftSize;
+    cfg.max_batch = (uint32_t)maxBatch;
+    if (devices.size() <= 1) {
+        if (!devices.empty()) cfg.device = devices[0];
+        check(mc_create(&cfg, &_engine), "mc_create");
+        return;
+    }
+    if (!mc_group_create) {
+        Log::error("conv", "%zu devices requested but the multi-device driver (libmcconv_rccl.so) is not linked in", devices.size());
+        std::abort();
+    }
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    if (mc_group_create(&cfg, devs.data(), (uint32_t)devs.size(), &_group) != MC_OK) {
+        Log::error("conv", "mc_group_create failed: %s", mc_group_last_error());
+        std::abort();
+    }
+    _engine = mc_group_engine(_group, 0);
+}
+
 Convolution::~Convolution() {
-    mc_destroy(_engine);
+    if (_group) mc_group_destroy(_group);  // (owns its engines)
+    else mc_destroy(_engine);
+    _group = nullptr;
     _engine = nullptr;
 }
 
@@ -40,7 +76,13 @@ void Convolution::onStart() {
 }
 
 void Convolution::prepare(size_t idx, const WavFile& wav, size_t nframes) {
-    check(mc_load_ir(_engine, idx, &wav.buffer[0].x, wav.numFrames, nframes), "mc_load_ir");
+    if (_group) {
+        if (mc_group_load_ir(_group, idx, &wav.buffer[0].x, wav.numFrames, nframes) != MC_OK) {
+            Log::error("conv", "mc_group_load_ir failed: %s", mc_group_last_error());
+            std::abort();
+        }
+    } else
+        check(mc_load_ir(_engine, idx, &wav.buffer[0].x, wav.numFrames, nframes), "mc_load_ir");
     if (idx + 1 > _nirs) _nirs = idx + 1;
 }
 
@@ -58,7 +100,13 @@ void Convolution::pushParams() {
         v.panDry = cc[i].value.panDry;
         v.panWet = cc[i].value.panWet;
         v.level = cc[i].value.level;
-        check(mc_set_params(_engine, i, &v), "mc_set_params");
+        if (_group) {
+            if (mc_group_set_params(_group, i, &v) != MC_OK) {
+                Log::error("conv", "mc_group_set_params failed: %s", mc_group_last_error());
+                std::abort();
+            }
+        } else
+            check(mc_set_params(_engine, i, &v), "mc_set_params");
     }
 }
 
@@ -79,6 +127,10 @@ void Convolution::onProcess(size_t nframes) {
     auto L = playback[0] ? (float*)jack_port_get_buffer(playback[0], nframes) : nullptr;
     auto R = playback[1] ? (float*)jack_port_get_buffer(playback[1], nframes) : nullptr;
     if (!in1 || !in2 || !L || !R) return;  // conv.cu:297
+    if (_group) {
+        Log::error("conv", "a Convolution over several devices renders batches only (processBatch)");
+        std::abort();
+    }
     if (nframes != _period) {  // jackd decides the period (256 on the README's target, 512 / 1024 in the run scripts)
         check(mc_set_period(_engine, (uint32_t)nframes), "mc_set_period");
         _period = nframes;
@@ -91,9 +143,15 @@ void Convolution::onProcess(size_t nframes) {
 void Convolution::processBatch(const float* in1, const float* in2, float* outL, float* outR, size_t nblocks) {
     pushParams();
     for (size_t done = 0; done < nblocks;) {
-        const size_t n = nblocks - done < 256 ? nblocks - done : 256;
-        check(mc_process_batch(_engine, in1 + done * 256, in2 + done * 256, outL + done * 256, outR + done * 256, n),
-              "mc_process_batch");
+        const size_t n = nblocks - done < _maxBatch ? nblocks - done : _maxBatch;
+        if (_group) {
+            if (mc_group_process_batch(_group, in1 + done * 256, in2 + done * 256, outL + done * 256, outR + done * 256, n) != MC_OK) {
+                Log::error("conv", "mc_group_process_batch failed: %s", mc_group_last_error());
+                std::abort();
+            }
+        } else
+            check(mc_process_batch(_engine, in1 + done * 256, in2 + done * 256, outL + done * 256, outR + done * 256, n),
+                  "mc_process_batch");
         done += n;
         pullVsteps();
         pushParams();

@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "gpu.h"
 #include "jackclient.h"
@@ -27,6 +28,7 @@
 // grid-stride launches; launch shapes are internal to the engine here.
 
 struct mc_engine;
+struct mc_group;
 
 class Convolution : public JackClient, public RawMidi::MessageHandler {
 public:
@@ -48,6 +50,10 @@ public:
     } cc[2];
 
     Convolution(const std::string& name = "Conv", size_t fftSize = CONV_DEFAULT_FFTSIZE);
+    // More than one device (no reference equivalent: gpu.cu:38-90 selects one): the IR partitions are sharded over `devices`
+    // and the partial wet blocks summed over RCCL (include/mcconv_group.h; needs libmcconv_rccl.so linked in).  Offline
+    // rendering (processBatch) only: a JACK period does not wait for a collective.  One device = the constructor above.
+    Convolution(const std::string& name, size_t fftSize, const std::vector<int>& devices, size_t maxBatch = 4096);
     ~Convolution();
 
     JackPort capture[2];
@@ -67,7 +73,9 @@ public:
 
 private:
     mc_engine* _engine = nullptr;
+    mc_group* _group = nullptr;  // != null: several devices; _engine is rank 0's engine (parameters are read back from it)
     size_t _fftSize;
+    size_t _maxBatch = 256;
     size_t _nirs = 0;
     size_t _period = 256;
     size_t _pushedVsteps[2] = {0, 0};  // cc[i].value.vsteps as last handed to the engine (see pullVsteps)

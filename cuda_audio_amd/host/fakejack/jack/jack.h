@@ -50,6 +50,13 @@ void fakejack_configure(jack_nframes_t sample_rate, jack_nframes_t period);
  * the output buffers.  Returns the number of periods processed. */
 typedef void (*fakejack_io_fn)(uint64_t period, float** bufs, size_t nbufs, jack_nframes_t nframes, void* user);
 uint64_t fakejack_run(jack_client_t* c, uint64_t nperiods, fakejack_io_fn feed, fakejack_io_fn drain, void* user);
+/* The same for several clients AT ONCE, as jackd runs them: every client gets a driver thread of its own that calls its process
+ * callback once per period (jackclient.cu:4-11: one real-time thread per client; main.cu:31-39 opens conv.count / 2 of
+ * them on one GPU).  users[i] is passed to client i's feed / drain.  spacing_us > 0: a thread starts period k no earlier than
+ * k * spacing_us after the common start (the period clock; 0 = back to back).  us_per_period[i] (may be null) receives client i's
+ * mean time inside its process callback.  Returns the periods every client completed. */
+uint64_t fakejack_run_all(jack_client_t** clients, size_t nclients, uint64_t nperiods, fakejack_io_fn feed, fakejack_io_fn drain,
+                          void** users, double spacing_us, double* us_per_period);
 /* simulate the server going away: invokes the shutdown callback */
 void fakejack_shutdown(jack_client_t* c);
 

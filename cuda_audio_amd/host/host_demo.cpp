@@ -4,7 +4,7 @@
 // MIDI controller messages, and raw float32 input/output files.
 //
 //   mcconv_host_demo <fftSize> <in.f32> <out.f32> <nperiods> <ir0.wav> [<ir1.wav>]
-//                    [--period 256|512|1024] [--set half key value]... [--cc half controller value @period]...
+//                    [--period 256|512|1024] [--devices a,b,...] [--set half key value]... [--cc half controller value @period]...
 // in.f32 holds [2][nperiods*period] floats (channel-major); out.f32 likewise.
 #include <cassert>
 #include <cstdio>
@@ -55,6 +55,16 @@ int main(int argc, char** argv) {
     unsigned period = 256;
     for (int i = 5; i + 1 < argc; i++)
         if (!strcmp(argv[i], "--period")) period = (unsigned)atoi(argv[i + 1]);
+    // --devices a,b,...: render offline (Convolution::processBatch) on a Convolution over several devices (IR partitions
+    // sharded, partial wet blocks summed over RCCL - include/mcconv_group.h; listing a device twice makes virtual ranks)
+    std::vector<int> devices;
+    for (int i = 5; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--devices"))
+            for (const char* p = argv[i + 1]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
     fakejack_configure(44100, period);
     Io io;
     io.n = nblocks * period;
@@ -67,7 +77,9 @@ int main(int argc, char** argv) {
     assert(got == io.in.size());
 
     selectGpu();
-    Convolution conv("demo", fftSize);
+    Convolution single("demo", devices.size() > 1 ? 4096 : fftSize);  // (placeholder when a device list is given)
+    Convolution* multi = devices.size() > 1 ? new Convolution("demo", fftSize, devices, 1024) : nullptr;
+    Convolution& conv = multi ? *multi : single;
     RawMidi::Device midi("fake:0");
     midi.handler = &conv;
     io.conv = &conv;
@@ -104,7 +116,7 @@ int main(int argc, char** argv) {
             else if (key == "level") val.level = (float)v;
             else { fprintf(stderr, "unknown key %s\n", key.c_str()); return 2; }
             a += 3;
-        } else if (!strcmp(argv[a], "--period") && a + 1 < argc) {
+        } else if ((!strcmp(argv[a], "--period") || !strcmp(argv[a], "--devices")) && a + 1 < argc) {
             a += 1;
         } else if (!strcmp(argv[a], "--cc") && a + 4 < argc) {
             CcEvent e{atoi(argv[a + 1]), atoi(argv[a + 2]), atoi(argv[a + 3]), strtoull(argv[a + 4] + 1, nullptr, 10)};
@@ -112,15 +124,22 @@ int main(int argc, char** argv) {
             a += 4;
         }
     }
-    conv.start();
-    const uint64_t done = fakejack_run(conv.handle, nblocks, feed, drain, &io);
-    assert(done == nblocks);
-    const double avg = conv.avgRuntime();
-    conv.stop();
+    uint64_t done = nblocks;
+    double avg = 0.0;
+    if (multi) {
+        conv.processBatch(io.in.data(), io.in.data() + io.n, io.out.data(), io.out.data() + io.n, nblocks * (period / 256));
+    } else {
+        conv.start();
+        done = fakejack_run(conv.handle, nblocks, feed, drain, &io);
+        assert(done == nblocks);
+        avg = conv.avgRuntime();
+        conv.stop();
+    }
     f = fopen(argv[3], "wb");
     assert(f);
     fwrite(io.out.data(), sizeof(float), io.out.size(), f);
     fclose(f);
     printf("blocks %llu avg_runtime_ms %.4f\n", (unsigned long long)done, avg);
+    delete multi;
     return 0;
 }

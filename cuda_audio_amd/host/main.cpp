@@ -4,7 +4,10 @@
 // start, connect ports, wait for a key, report the average runtime.
 // Built against the fake JACK of this directory it runs offline:
 // `mcconv_host --periods N` drives N periods of synthetic input instead of
-// waiting on stdin.
+// waiting on stdin - all instances AT ONCE, a driver thread per client, as jackd
+// runs them (--sequential: one after the other; --period F: frames per period;
+// --spacing US: a period clock; --dump PREFIX: every instance's input and output
+// as raw float32 files PREFIX<i>.in1 / .in2 / .outL / .outR).
 #include <cassert>
 #include <cstdlib>
 #include <cstring>
@@ -20,9 +23,16 @@
 int main(int argc, char** argv) {
     uint64_t periods = 0;
     const char* settingsPath = "settings.txt";
+    const char* dump = nullptr;
+    bool sequential = false;
+    double spacing_us = 0.0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--periods") && i + 1 < argc) periods = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--settings") && i + 1 < argc) settingsPath = argv[++i];
+        else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
+        else if (!strcmp(argv[i], "--sequential")) sequential = true;
+        else if (!strcmp(argv[i], "--spacing") && i + 1 < argc) spacing_us = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--period") && i + 1 < argc) fakejack_configure(44100, (jack_nframes_t)atoi(argv[++i]));
     }
     selectGpu();
 
@@ -85,17 +95,52 @@ int main(int argc, char** argv) {
     }
 
     if (periods) {
-        // offline: the fake JACK server pushes seeded noise through every instance
+        // offline: the fake JACK server pushes seeded noise through every instance (its own stream of noise each), all
+        // instances at once unless --sequential
         struct Feed {
-            std::mt19937 rng{1234};
+            std::mt19937 rng;
             std::uniform_real_distribution<float> u{-0.25f, 0.25f};
-        } feed;
+            std::vector<float> rec[4];  // in1, in2, outL, outR when dumping
+            bool keep = false;
+        };
+        std::vector<Feed> feeds(instances.size());
+        std::vector<void*> users;
+        std::vector<jack_client_t*> clients;
+        for (size_t i = 0; i < instances.size(); i++) {
+            feeds[i].rng.seed(1234 + 17 * (unsigned)i);
+            feeds[i].keep = dump != nullptr;
+            users.push_back(&feeds[i]);
+            clients.push_back(instances[i]->handle);
+        }
         auto fill = [](uint64_t, float** bufs, size_t n, jack_nframes_t nframes, void* user) {
             auto* f = static_cast<Feed*>(user);
             for (size_t b = 0; b < n; b++)
-                for (jack_nframes_t s = 0; s < nframes; s++) bufs[b][s] = f->u(f->rng) + 0.01f;
+                for (jack_nframes_t s = 0; s < nframes; s++) {
+                    bufs[b][s] = f->u(f->rng) + 0.01f;
+                    if (f->keep && b < 2) f->rec[b].push_back(bufs[b][s]);
+                }
         };
-        for (auto* c : instances) fakejack_run(c->handle, periods, fill, nullptr, &feed);
+        auto keep = [](uint64_t, float** bufs, size_t n, jack_nframes_t nframes, void* user) {
+            auto* f = static_cast<Feed*>(user);
+            if (!f->keep) return;
+            for (size_t b = 0; b < n && b < 2; b++) f->rec[2 + b].insert(f->rec[2 + b].end(), bufs[b], bufs[b] + nframes);
+        };
+        std::vector<double> us(instances.size(), 0.0);
+        if (sequential)
+            for (size_t i = 0; i < instances.size(); i++) fakejack_run_all(&clients[i], 1, periods, fill, keep, &users[i], spacing_us, &us[i]);
+        else
+            fakejack_run_all(clients.data(), clients.size(), periods, fill, keep, users.data(), spacing_us, us.data());
+        for (size_t i = 0; i < instances.size(); i++) {
+            Log::info(instances[i]->name, "%s: %.2f us per period inside the process callback (%llu periods)", sequential ? "alone" : "concurrent",
+                      us[i], (unsigned long long)periods);
+            if (dump) {
+                static const char* ext[4] = {"in1", "in2", "outL", "outR"};
+                for (int k = 0; k < 4; k++) {
+                    std::ofstream f(std::string(dump) + std::to_string(i) + "." + ext[k], std::ios::binary);
+                    f.write(reinterpret_cast<const char*>(feeds[i].rec[k].data()), (std::streamsize)(feeds[i].rec[k].size() * sizeof(float)));
+                }
+            }
+        }
     } else {
         std::cin.get();
     }

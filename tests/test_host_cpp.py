@@ -152,37 +152,96 @@ def test_convolution_class_with_512_frame_period(host_built, oracle_mod, tmp_pat
 
 
 @pytest.mark.gpu
-def test_main_flow_with_settings_file(host_built, tmp_path):
+def test_convolution_class_over_several_devices(host_built, oracle_mod, tmp_path):
+    """The C++ Convolution with a device list (conv.h): IR partitions sharded over the devices by the native driver
+    (libmcconv_rccl.so, include/mcconv_group.h), offline rendering through processBatch.  Two virtual ranks on the one card of
+    this box (--devices 0,0: the sum kernel stands in for RCCL) against the oracle."""
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    nb, n_ref = 700, 16384
+    x = make_input(nb * 256)
+    wavs, decoded = [], []
+    for i, taps in enumerate((9000, 7000)):
+        w = str(tmp_path / f"ir{i}.wav")
+        _write_wav(w, make_ir(taps, seed=11 + i, norm=0.05), 24)
+        wavs.append(w)
+        subprocess.check_call([TOOL, "wavdump", w, str(tmp_path / "d.f32")], stdout=subprocess.DEVNULL)
+        decoded.append(np.fromfile(str(tmp_path / "d.f32"), np.float32).reshape(-1, 2))
+    x.tofile(str(tmp_path / "in.f32"))
+    cmd = [DEMO, str(n_ref), str(tmp_path / "in.f32"), str(tmp_path / "out.f32"), str(nb)] + wavs
+    cmd += ["--devices", "0,0", "--set", "1", "select", "1", "--set", "0", "predelay", "512", "--set", "0", "panWet", "0.5"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr + res.stdout
+    got = np.fromfile(str(tmp_path / "out.f32"), np.float32).reshape(2, -1)
+    ref = oracle_mod.RefCompat(n_ref, True)
+    for i, d in enumerate(decoded):
+        ref.prepare(i, d)
+    ref.set(1, select=1)
+    ref.set(0, predelay=512, panWet=0.5)
+    want = ref.process(x[0], x[1])
+    assert rms(want) > 0.05
+    assert rms(got - want) <= RMS_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period", [256, 512])
+def test_main_flow_with_settings_file(host_built, oracle_mod, tmp_path, period):
     """mcconv_host = the reference's main() order (main.cu:18-116): selectGpu, settings.txt, one Convolution per
     channel pair, MIDI mapping + initial values, IR bank from an index file, start, connect, run, avg runtime.
-    Two pairs (conv.count 4) to exercise several instances on one GPU (main.cu:31-39)."""
+    Two pairs (conv.count 4) run AT THE SAME TIME on one GPU, each on its own driver thread of the fake JACK server - what
+    jackd does with the reference's instances (main.cu:31-39, jackclient.cu:4-11): two engines each parking a period on the
+    card, polling their own doorbells.  Every instance's output (dumped by the host together with the noise it was fed)
+    is the oracle's for that input, IR bank and initial values; the same again with the instances one after the other."""
     from cuda_audio_amd.synth import make_ir
 
-    wavs = []
+    wavs, decoded = [], []
     for j, bits in enumerate((16, 24, 16)):
         w = tmp_path / f"ir{j}.wav"
         _write_wav(str(w), make_ir(3000 + 700 * j, seed=70 + j, norm=0.05), bits)
         wavs.append(str(w))
+        subprocess.check_call([TOOL, "wavdump", str(w), str(tmp_path / "d.f32")], stdout=subprocess.DEVNULL)
+        decoded.append(np.fromfile(str(tmp_path / "d.f32"), np.float32).reshape(-1, 2))
     index = tmp_path / "all.index"
     index.write_text("\n".join(wavs) + "\n")
+    n_ref = 16384
     lines = ["# generated by the test", "conv.count 4"]
     for i in range(4):
-        lines += [f"conv[{i}].fftSize 16384", f"conv[{i}].maxPredelay 8192", f"conv[{i}].index {index}",
+        lines += [f"conv[{i}].fftSize {n_ref}", f"conv[{i}].maxPredelay 8192", f"conv[{i}].index {index}",
                   f"conv[{i}].input system:capture_{i + 1}", f"conv[{i}].output system:playback_{i + 1}",
                   f"conv[{i}].cc.device hw:2,0", f"conv[{i}].cc.message 176", f"conv[{i}].cc.select 21",
                   f"conv[{i}].cc.predelay 22", f"conv[{i}].cc.dry 23", f"conv[{i}].cc.wet 24", f"conv[{i}].cc.speed 25",
                   f"conv[{i}].cc.panDry {26 + i % 2}", f"conv[{i}].cc.panWet {26 + i % 2}", f"conv[{i}].cc.level 28",
                   f"conv[{i}].value.select {i % 3}", f"conv[{i}].value.predelay 1024", f"conv[{i}].value.dry 0.5",
-                  f"conv[{i}].value.wet 0.5", f"conv[{i}].value.speed 100", f"conv[{i}].value.panDry 0",
-                  f"conv[{i}].value.panWet 0", f"conv[{i}].value.level 1.0"]
+                  f"conv[{i}].value.wet {0.5 + 0.1 * (i // 2)}", f"conv[{i}].value.speed 100", f"conv[{i}].value.panDry 0",
+                  f"conv[{i}].value.panWet {0.25 * (i % 2)}", f"conv[{i}].value.level 1.0"]
     settings = tmp_path / "settings.txt"
     settings.write_text("\n".join(lines) + "\n")
-    res = subprocess.run([os.path.join(HOST, "mcconv_host"), "--settings", str(settings), "--periods", "60"],
-                         capture_output=True, text=True, cwd=str(tmp_path))
-    assert res.returncode == 0, res.stderr[-2000:]
-    out = res.stdout + res.stderr
-    assert out.count("Average convolution runtime") == 2
-    assert "Selected GPU" in out
+    nper = 420  # (the cold-start ramp settles after ~160 calls: from then on both instances park their periods)
+    for mode in ("concurrent", "sequential"):
+        prefix = str(tmp_path / f"{mode}_")
+        cmd = [os.path.join(HOST, "mcconv_host"), "--settings", str(settings), "--periods", str(nper), "--period", str(period), "--dump", prefix]
+        if mode == "sequential":
+            cmd.append("--sequential")
+        res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = res.stdout + res.stderr
+        assert out.count("Average convolution runtime") == 2
+        assert "Selected GPU" in out
+        assert out.count("us per period inside the process callback") == 2
+        for n in range(2):
+            io = [np.fromfile(f"{prefix}{n}.{e}", np.float32) for e in ("in1", "in2", "outL", "outR")]
+            assert all(len(a) == nper * period for a in io)
+            ref = oracle_mod.RefCompat(n_ref, True)
+            for j, d in enumerate(decoded):
+                ref.prepare(j, d)
+            for h in range(2):
+                i = 2 * n + h
+                ref.set(h, select=i % 3, predelay=1024, dry=0.5, wet=0.5 + 0.1 * (i // 2), speed=100, panDry=0.0, panWet=0.25 * (i % 2), level=1.0)
+            want = ref.process(io[0], io[1], block=period)
+            err = rms(np.stack(io[2:]) - want)
+            assert rms(want) > 0.05
+            assert err <= RMS_TOL, f"{mode}, instance {n}, period {period}: rms {err:.3e}"
+        print(mode, period, [ln for ln in out.splitlines() if "us per period" in ln])
 
 
 def test_operators_subset(host_built):
