@@ -97,6 +97,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each batch before starting the next")
     ap.add_argument("--pipeline", action="store_true",
                     help="mc_config.pipeline: post stage of batch k on a second stream under the MAC of batch k + 1")
+    ap.add_argument("--no-literal-mac", action="store_true", help="skip the literal partition x bin MAC record (streaming kernel, 2048-block launches)")
     ap.add_argument("--no-direct-mac", action="store_true", help="N > 1: skip the third curve (partition shards with the literal resident MAC)")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the untimed comparison of the sharded pipeline with an unsharded engine on rank 0")
@@ -687,10 +688,19 @@ def main():
                     chunk = 16384 - int(ks["partitions"])  # overlap-save form: blocks per segment
                 if lv in (254, 255):
                     chunk = (8192 if lv == 254 else 16384) - int(ks["partitions"]) + 1
-                where = [(0, 64)]  # first blocks of the launch: their windows and overlap-add reach into the previous step
+                # >= 2048 blocks spread over the whole step: the first blocks of the launch (their windows reach into the previous
+                # step), across every segment / chunk boundary of the form that ran, the middle of every segment / chunk, the batch end
+                where = [(0, 64)]
                 if chunk and chunk + 32 < T:
-                    where.append((chunk - 32, 64))  # across the first chunk boundary of the second-level transform
-                where.append((T - 64, 64))  # the batch end
+                    nch = -(-T // chunk)
+                    per = max(32, -(-2048 // (2 * nch)) // 16 * 16)
+                    for c in range(nch):
+                        if c > 0:
+                            where.append((c * chunk - per // 2, per))
+                        mid = c * chunk + min(chunk, T - c * chunk) // 2
+                        if mid + per <= T - 64:
+                            where.append((mid, per))
+                where.append((T - 64, 64))
                 res["parity"] = oracle_parity(a, eng.irs[0], [bench_params(0), bench_params(1)], excerpt, T, got, where)
 
         if multi:
@@ -819,6 +829,48 @@ def main():
             e.set_period(BLOCK)
             latency["longer_periods"] = longer
             res["latency_mode"] = latency
+
+        # ---- the literal partition x bin MAC in throughput mode (north star: "the partition x bin complex-MAC kept as a
+        # bandwidth-bound reduction ... evidenced by rocprof achieved-HBM-GB/s"): the streaming kernel over 2048-block batches,
+        # every block re-reading its 4 IR paths and 2 delay-line inputs (21.17 MB per block at P = 1723)
+        if not a.no_literal_mac and a.mode == "resident" and a.precision == "fp32" and npairs == 1:
+            keep_mode = a.mode
+            a.mode = "stream"
+            Tl = min(2048, a.max_blocks)
+            lit = Pairs(a, local, 1, Tl)
+            a.mode = keep_mode
+            le = lit[0]
+            le.use_torch_stream(comp)
+            lo = torch.zeros(2, Tl * BLOCK, device=dev)
+            for k in range(3):
+                le.process_device(d_in[0][0, k * Tl * BLOCK:].data_ptr(), d_in[0][1, k * Tl * BLOCK:].data_ptr(), lo[0].data_ptr(), lo[1].data_ptr(), Tl)
+            torch.cuda.synchronize()
+            le.enable_kernel_timing(True)
+            le.kernel_stats(reset=True)
+            nl = 8
+            t1 = time.perf_counter()
+            for k in range(nl):
+                le.process_device(d_in[0][0, (k % 4) * Tl * BLOCK:].data_ptr(), d_in[0][1, (k % 4) * Tl * BLOCK:].data_ptr(), lo[0].data_ptr(), lo[1].data_ptr(), Tl)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t1
+            lks = le.kernel_stats()
+            le.enable_kernel_timing(False)
+            ab = le.algorithmic_bytes_per_block()
+            kavg = lks["total_ms"] / max(lks["launches"], 1)
+            prof = labelled_profile("r4_literal_mac.json")
+            res["literal_mac"] = {
+                "kernel": "k_mac_stream", "blocks_per_launch": Tl, "rtf": round(nl * Tl * BLOCK / FS / dtl, 1), "ms_per_step": round(dtl / nl * 1e3, 4),
+                "kernel_avg_ms": round(kavg, 5), "kernel_launches": lks["launches"], "partitions": lks["partitions"],
+                "survey_8d_bytes_per_block": ab, "survey_8d_GBps": round(ab * Tl / (kavg * 1e-3) / 1e9, 1) if kavg > 0 else None,
+                "frac_of_hbm_peak": round(ab * Tl / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if kavg > 0 else None,
+                "note": "the partition x bin MAC as written in SURVEY 8(d) - lanes = partitions, every block re-reads the IR spectra and the "
+                        "delay-line window - 2048 blocks per launch; its 21 MB working set is served by L2 / Infinity Cache, so the "
+                        "SURVEY-8(d) byte rate exceeds the HBM peak (the committed rocprofv3 FETCH_SIZE of this launch says how little "
+                        "reaches the memory side); at one block per launch (latency_mode) the same kernel reads HBM-class latency",
+            }
+            if prof:
+                res["literal_mac"]["memory_side_traffic"] = prof
+            lit.close()
 
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(eng.irs[0][0], eng.irs[0][1], xs[0], a.cpu_seconds)
@@ -1224,8 +1276,14 @@ def main():
                        **({"note": "fp16 storage exists for the literal streaming MAC only (an HBM stress, BASELINE config 5); the engine's "
                                    "fast path for this configuration is fp32 with the second-level transform (profiles/r2_bench_cfg5_fp32.json), "
                                    "two orders of magnitude faster"} if a.precision == "fp16" else {})},
+            "value_host_visible": (r.get("host_io") or {}).get("rtf"),
+            "value_clauses": {"value": "SURVEY 8(d) throughput mode with inputs and outputs resident in HBM (the prompt's `value`: inputs already in HBM "
+                                       "when the timed region starts); NOT 8(d)'s 'output fully produced in host-visible memory'",
+                              "value_host_visible": "the same path through pinned HOST buffers in and out (mc_process_batch; PCIe both ways, bound by the link): "
+                                                    "8(d)'s host-visible clause; = host_io.rtf"},
             "roofline": roofline,
             "parity": r.get("parity"),
+            "literal_mac": r.get("literal_mac"),
             "cpu_baseline": r.get("cpu_baseline"),
             "host_io": r.get("host_io"),
             "latency_mode": r.get("latency_mode"),
