@@ -1457,8 +1457,11 @@ void corr_chunks(CorrArgs* ca, int T, int need_a0, int need_a1, int need_b0) {
 // window before it, no Q8 pass, no retired predelay epoch ringing out, the segments' history inside the live epoch.
 bool os_applies(const mc_engine* e, const Staged& st, int count, bool slice, const float* d_in1, const float* d_in2, const float* d_outL,
                 const float* d_outR, int* ovl_blocks) {
-    if (!e->os_on || e->half || e->pipelined || !e->fuse_out || !e->inv_to_wet || (e->sliced && !slice)) return false;
+    if (!e->os_on || e->pipelined || !e->fuse_out || !e->inv_to_wet || (e->sliced && !slice)) return false;
     if (e->cfg.part_begin || e->cfg.part_end || !d_outL || !d_outR || count < e->os_min_blocks || st.ctx.pstride != 0 || st.nact <= 0) return false;
+    // (mc_config.stream_threshold asks for the literal MAC below it; engines with fp16 storage keep it for the partition sweep of
+    // single periods and short batches - the spectra of this form come from the fp32 taps whatever the storage of the sweep)
+    if (!e->half && count < e->stream_threshold) return false;
     if ((reinterpret_cast<uintptr_t>(d_in1) | reinterpret_cast<uintptr_t>(d_in2) | reinterpret_cast<uintptr_t>(d_outL) | reinterpret_cast<uintptr_t>(d_outR)) & 15) return false;
     int pmax = 0;
     for (int a = 0; a < st.nact; a++) {

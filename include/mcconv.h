@@ -68,7 +68,9 @@ typedef struct {
     uint32_t stream_threshold; /* batches shorter than this use the streaming MAC kernel
                                (0 = default) */
     uint32_t precision;     /* 0 = fp32 spectra; 1 = fp16 storage of IR spectra and delay line for the
-                               partition sweep (fp32 products and sums; streaming kernel only) */
+                               partition sweep (fp32 products and sums; the streaming kernel: single periods and batches
+                               below 12288 blocks).  Longer settled batches take the overlap-save form in either precision
+                               (its spectra are built from the fp32 taps: fp32 accuracy there) */
     uint32_t period;        /* JACK period the host will call mc_process with: 0/256, 512 or 1024 frames.  The
                                reference's per-call semantics (cross-fade step, DC/Nyquist and tail-drop windows)
                                follow this size; internally a period is 1, 2 or 4 blocks of 256.  Batch calls
@@ -109,8 +111,11 @@ typedef struct {
     uint32_t fast_levels;   /* how the last long batch summed its partitions: 0 = direct-form MAC, 1..3 = fast-FIR form
                                with that many nested levels ((3/4)^levels of the multiply-adds); second-level transform
                                along the block axis instead of the MAC: 254 = its fused 8192-point form (one launch,
-                               k_g2_mac: the default for long batches with one set of gains), 255 = its split 16384-point
-                               form (k_f2_fwd + k_f2_prod: per-slot gains, IRs over 5632 partitions) */
+                               k_g2_mac: long batches with one set of gains where the overlap-save form does not apply),
+                               255 = its split 16384-point form (k_f2_fwd + k_f2_prod: per-slot gains, IRs over 5632
+                               partitions); 253 = overlap-save segments of 512 x 8192 frames (k_os_cols, k_os_rows, k_os_out:
+                               the default for whole or block-sliced batches of >= 12288 blocks with one set of gains
+                               outside the Q8 regime; `partitions` then holds the blocks of history per segment) */
     uint32_t reserved;
 } mc_kernel_stats;
 
@@ -211,11 +216,12 @@ int mc_enable_kernel_timing(mc_engine *e, int on); /* HIP events around the MAC 
 int mc_get_kernel_stats(mc_engine *e, mc_kernel_stats *out, int reset);
 uint64_t mc_algorithmic_bytes_per_block(const mc_engine *e); /* (4 paths + 2 inputs) * P * 2048 */
 uint64_t mc_blocks_processed(const mc_engine *e);
-/* Batch length (blocks, a multiple of 8, <= at_most and <= max_batch) that suits the loaded IRs best: long batches
- * take the sum over partitions as a second-level transform in chunks of 8192 - P16 + 1 blocks (16384 - P16 + 1 for
- * IRs over 2560 partitions; P16 = partitions of the longest loaded IR rounded up to 16), so whole chunks - minus one
- * block, the reach-back of a block slice - waste nothing.  at_most shorter than a chunk is returned as it is
- * (rounded down to 8).  No reference equivalent (batch calls are new). */
+/* Batch length (blocks, <= at_most and <= max_batch) that suits the loaded IRs best.  Batches of at least 12288 blocks and
+ * one segment run as overlap-save segments of 16384 - P16 blocks (P16 = partitions of the longest loaded IR rounded up
+ * to 16): whole segments waste nothing.  Below that the sum over partitions is a second-level transform in chunks of
+ * 8192 - P16 + 1 blocks (16384 - P16 + 1 for IRs over 2560 partitions): whole chunks minus one block (the reach-back
+ * of a block slice), a multiple of 8.  at_most shorter than a chunk is returned as it is (rounded down to 8).
+ * No reference equivalent (batch calls are new). */
 uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
 
 /* Diagnostics (tests only): copy `bytes` from an engine-owned device buffer to host.
@@ -226,7 +232,9 @@ uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
  * pair the last process call sampled / that was published last (uint64), 9 = batches in the Q8 regime by the form
  * their cut terms took {k_drop_fft, forward transforms, time-domain tiles} and JACK periods whose cut terms came with the
  * launch before theirs (4 x uint64), 10 = batch launches by the form
- * of their partition sums {fused, split second-level transform, resident MAC} (3 x uint64).  dims[0..3] receive
+ * of their partition sums {fused, split second-level transform, resident MAC} (3 x uint64), 11 = overlap-save form {batches that
+ * took it, builds of its spectra} (2 x uint64), 12 / 13 / 14 = its row buffer and spectra (float4), 15 = 1 when the library is the lab
+ * build (-DMCCONV_LAB: measurement switches and alternative kernels).  dims[0..3] receive
  * {pstride, ring, max_batch, wet ring length} when non-null. */
 int mc_debug_read(mc_engine *e, int which, uint64_t idx, void *dst, uint64_t offset_bytes, uint64_t bytes,
                   uint64_t dims[4]);

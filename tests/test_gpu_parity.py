@@ -885,6 +885,42 @@ def test_config5_fp16_full_length_30s(gpu_lib):
     c.close()
 
 
+def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib):
+    """mc_config.precision = 1 keeps IR spectra and delay line in fp16 for the partition sweep (single periods, short batches).
+    A long settled batch runs as overlap-save segments in either precision - the form's spectra are built from the fp32 taps - so an
+    fp16 engine's long batches are the fp32 engine's (1e-6), and the periods that follow go back to the fp16 sweep on the
+    delay-line slots the form left (fp16 tolerance)."""
+    import torch
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    n_ref, taps, T = 131072, 88200, 13000
+    x = make_input((3 * T + 4) * 256)
+    ir = make_ir(taps, seed=5678)
+    dx = torch.from_numpy(x).cuda()
+    outs, levels, per = [], [], []
+    for prec in ("fp32", "fp16"):
+        c = _conv(fftSize=n_ref, max_batch=T, precision=prec)
+        c.prepare(0, ir)
+        apply_params(c, dict(BASE), dict(BASE), False)
+        c.enable_kernel_timing(True)
+        o = torch.zeros(3, 2, T * 256, device="cuda")
+        lv = []
+        for k in range(3):
+            c.process_device(dx[0, k * T * 256:].data_ptr(), dx[1, k * T * 256:].data_ptr(), o[k, 0].data_ptr(), o[k, 1].data_ptr(), T)
+            c.sync()
+            lv.append(c.kernel_stats()["fast_levels"])
+        outs.append(o.cpu().numpy())
+        levels.append(lv)
+        a = 3 * T * 256
+        per.append(np.concatenate([np.stack(c.onProcess(x[0, a + 256 * j:a + 256 * (j + 1)], x[1, a + 256 * j:a + 256 * (j + 1)])) for j in range(4)], axis=1))
+        c.close()
+    assert levels[0][1:] == [253, 253] and levels[1][1:] == [253, 253], levels
+    assert rms(outs[1][1:] - outs[0][1:]) <= 1e-6
+    wet = rms(per[0]) * 0.5
+    assert rms(per[1] - per[0]) <= FP16_REL_TOL * wet + 1e-6
+
+
 def test_error_behaviour_and_edge_cases(oracle_mod, gpu_lib):
     """Boundary behaviour of the C ABI: wrong period length, missing IR, oversize batch, oversize IR capacity,
     IR longer than N_ref - 1024 (truncated like conv.cu:239), reset."""
