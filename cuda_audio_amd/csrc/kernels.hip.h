@@ -125,7 +125,8 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
                                              int need_a0, int need_a1, int need_b0,
                                              int hist_from,  // input history is kept from this block on (see run_front)
                                              int t_base,     // first block of this launch (a block-sliced rank launches its ranges)
-                                             DropAhead da) { // DA: the cut terms of output block t + da.shift (see DropAhead)
+                                             DropAhead da,   // DA: the cut terms of output block t + da.shift (see DropAhead)
+                                             int store_from = 0) {  // blocks before this one leave no delay-line slot (the overlap-save form keeps the batch's tail only; their cut terms and histories are still produced)
     // Block-sliced engines transform only the blocks some window of theirs can reach: t in [need_a0, need_a1) or
     // t >= need_b0 (the tail the next call reaches back to).  The others get zero Q1/Q2 sums and nothing else.
     __shared__ float2 s_tw[FFT_N];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(XF_THREADS) void k_fwd(const float* __restrict__ in
     for (int idx = threadIdx.x; idx < MC_NB * FWD_TILE; idx += XF_THREADS) {
         int tb = idx & (FWD_TILE - 1), k = idx >> FWD_TILE_LOG2;
         int t = tb0 + tb;
-        if (t < T && needed(t)) {
+        if (t < T && needed(t) && t >= store_from) {
             const size_t at = (size_t)k * ring + ((slot0 + t) & (ring - 1));
             fdl[at] = s_tile[k][tb];
             if (fdl16) fdl16[at] = pack_half4(s_tile[k][tb], FDL16_SCALE);

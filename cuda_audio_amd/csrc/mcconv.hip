@@ -1407,7 +1407,7 @@ int retire_epoch(mc_engine* e, uint64_t new_delay, bool force = false) {
         hipLaunchKernelGGL(k_fwd<false>, dim3((Tc + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, (const float*)nullptr,
                            (const float*)nullptr, 1, (int64_t)0, Tc, e->d_fdl, e->ring, slot0, (const BlockParams*)nullptr, 0,
                            (float4*)nullptr, (float4*)nullptr, e->d_tw, e->d_fdl16, (float*)nullptr, 0, (float4*)nullptr, 0,
-                           (int64_t)0, 0, Tc, Tc, 0, 0, DropAhead());
+                           (int64_t)0, 0, Tc, Tc, 0, 0, DropAhead(), 0);
         MacOut mo;
         rc = launch_mac_batch(e, act, nact, true, Tc, slot0, &mo);
         if (rc) return rc;
@@ -1453,10 +1453,11 @@ void corr_chunks(CorrArgs* ca, int T, int need_a0, int need_a1, int need_b0) {
 // ---------------------------------------------------------------------------
 // Long settled batches as overlap-save segments (ossave.hip.h).
 // ---------------------------------------------------------------------------
-// Can this whole batch take the form?  One fp32 engine finishing its own output, one set of gains over the batch and the
-// window before it, no Q8 pass, no retired predelay epoch ringing out, the segments' history inside the live epoch.
+// Can this whole batch take the form?  One engine finishing its own output, one set of gains over the batch and the
+// window before it, no retired predelay epoch ringing out, the segments' history inside the live epoch; in the Q8 regime only
+// the shipped shape (every output block loses ONE term of ONE source block: the forward transforms sum the cut terms, q8_ok).
 bool os_applies(const mc_engine* e, const Staged& st, int count, bool slice, const float* d_in1, const float* d_in2, const float* d_outL,
-                const float* d_outR, int* ovl_blocks) {
+                const float* d_outR, bool q8_ok, int* ovl_blocks) {
     if (!e->os_on || e->pipelined || !e->fuse_out || !e->inv_to_wet || (e->sliced && !slice)) return false;
     if (e->cfg.part_begin || e->cfg.part_end || !d_outL || !d_outR || count < e->os_min_blocks || st.ctx.pstride != 0 || st.nact <= 0) return false;
     // (mc_config.stream_threshold asks for the literal MAC below it; engines with fp16 storage keep it for the partition sweep of
@@ -1473,7 +1474,7 @@ bool os_applies(const mc_engine* e, const Staged& st, int count, bool slice, con
     if (pmax <= 0 || (int64_t)ovl * MC_B > OS_N / 2) return false;  // (a segment at least half new frames)
     if (e->res_end > e->t_front * MC_B) return false;
     if (e->epoch_b0 != 0 && e->epoch_b0 + (uint64_t)pmax > e->t_front) return false;
-    if (make_taildrop(e, st.ctx.vir, st.ctx.predelay).on) return false;
+    if (!q8_ok) return false;  // (Q8 regime in a shape whose cut terms the forward transforms cannot sum themselves)
     *ovl_blocks = ovl;
     return true;
 }
@@ -1568,7 +1569,7 @@ int ensure_os(mc_engine* e, const Staged& st, int nseg) {
 // the partitioned passes would: the last blocks' delay-line slots, slot gains and histories (k_fwd over the batch's tail), the
 // Q1/Q2 prefix ring, the wet ring where later calls reach, and the last block's segment (its second half opens the next call).
 int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const float* d_in1, const float* d_in2, float* d_outL, float* d_outR,
-           int T, int ovl_blocks, int slot0, bool slice, int first, int count, int halo) {
+           int T, int ovl_blocks, int slot0, bool slice, int first, int count, int halo, const DropAhead* q8_da, int q8_shift) {
     // whole batch: wet frames of blocks [0, T).  Block-sliced: of the slice and the reach-back blocks before it (predelay),
     // the segments' history read from the batch's own buffers in front of the window
     const int w0 = slice ? first - halo : 0, wn = slice ? count + halo : T;
@@ -1595,9 +1596,23 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         // (its partition sums from the delay line, one inverse transform: its second half opens the next call)
         const int reach = std::max(round_up(e->Pcap, 16) + 64, (int)((e->cfg.n_ref + MC_MAX_PREDELAY) / MC_B) + 8);
         const int from = std::max(0, T - reach) & ~(FWD_TILE - 1);
-        hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
-                           e->d_fdl, e->ring, slot0, d_ptab, 0, (float4*)nullptr, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
-                           e->rc, (int64_t)e->t_front, 0, 0, from, hist_from, from, da);
+        if (q8_shift >= 0) {
+            // Q8 regime at the shipped shape: the forward transforms of ALL blocks sum the cut terms of output block t + shift while
+            // X_t is in registers (k_fwd<true>, DropAhead) - delay-line slots still only for the tail; the first `shift` output
+            // blocks, whose source lies before the batch, through k_drop_fft from the slots the previous call left
+            hipLaunchKernelGGL(k_fwd<true>, dim3((T + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
+                               e->d_fdl, e->ring, slot0, d_ptab, 0, (float4*)nullptr, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
+                               e->rc, (int64_t)e->t_front, 0, T, T, hist_from, 0, *q8_da, from);
+            const TailDrop tdq = make_taildrop(e, st.ctx.vir, st.ctx.predelay);
+            const int nd = std::min(T, q8_shift);
+            hipLaunchKernelGGL(k_drop_fft, dim3((nd + DF_WAVES - 1) / DF_WAVES), dim3(64 * DF_WAVES), 0, side, tdq, e->d_dropbuf, (int64_t)st.ctx.t0, 0, nd,
+                               (int64_t)st.ctx.predelay, (int64_t)e->cfg.n_ref, e->pm, (int64_t)e->epoch_b0);
+            (q8_shift < T ? e->n_drop_ahead : e->n_drop_fft)++;
+            stored.drop_done = true;
+        } else
+            hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
+                               e->d_fdl, e->ring, slot0, d_ptab, 0, (float4*)nullptr, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
+                               e->rc, (int64_t)e->t_front, 0, 0, from, hist_from, from, da, 0);
         MacOut mo;
         const uint64_t b = e->t_front + (uint64_t)T - 1;
         e->stream = side;  // (the MAC and inverse-transform launchers use the engine's stream)
@@ -1610,7 +1625,7 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
         const int from = stored.need_b0 & ~(FWD_TILE - 1);
         hipLaunchKernelGGL(k_fwd<false>, dim3((T - from + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, side, d_in1, d_in2, 1, (int64_t)T * MC_B, T,
                            e->d_fdl, e->ring, slot0, d_ptab, 0, st.d_sums, e->d_slotgain, e->d_tw, e->d_fdl16, e->d_xhist, e->xr, e->d_gring,
-                           e->rc, (int64_t)e->t_front, 0, 0, stored.need_b0, hist_from, from, da);
+                           e->rc, (int64_t)e->t_front, 0, 0, stored.need_b0, hist_from, from, da, 0);
     }
     const int head = slice ? 0 : (int)std::min<uint64_t>((uint64_t)T, (st.ctx.predelay + MC_B - 1) / MC_B);
     OutArgs oa;
@@ -1630,6 +1645,7 @@ int run_os(mc_engine* e, const Staged& st, mc_engine::BatchCtx& stored, const fl
     oa.compat = (int)e->cfg.compat;
     oa.pm = e->pm;
     oa.blk0 = 0;
+    oa.drop = (!slice && q8_shift >= 0) ? e->d_dropbuf : nullptr;
     if (slice) {  // the slice [first, first + count), nothing else; a sliced engine keeps no wet history
         oa.out_from = first;
         oa.out_end = first + count;
@@ -1797,8 +1813,22 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
     {  // long settled batches: overlap-save segments instead of the three passes below (ossave.hip.h)
         int os_ovl = 0;
         const int halo_full = (int)((st.ctx.predelay + MC_B - 1) / MC_B) + 1;
-        if (!lin && !piped && to_wet && (!slice || halo == halo_full || wblock == 0) && os_applies(e, st, count, slice, d_in1, d_in2, d_outL, d_outR, &os_ovl)) {
-            const int rc = run_os(e, st, e->pipe[(e->pipe_head + e->pipe_count) % kPipe], d_in1, d_in2, d_outL, d_outR, T, os_ovl, slot0, slice, first, count, halo);
+        const bool os_shape = !lin && !piped && to_wet && (!slice || halo == halo_full || wblock == 0);
+        DropAhead os_da;
+        std::memset(&os_da, 0, sizeof(os_da));
+        int os_shift = -1;
+        bool q8_ok = true;
+        if (os_shape && count >= e->os_min_blocks && make_taildrop(e, st.ctx.vir, st.ctx.predelay).on) {
+            q8_ok = false;
+            if (!slice && e->os_on && e->fuse_drop && e->drop_ahead && e->pm == 1 && e->epoch_b0 <= e->t_front && e->res_end <= e->t_front * MC_B) {
+                const int rc_t = plan_drop_ahead(e, st.ctx.vir, st.ctx.predelay, &os_da, &os_shift);
+                if (rc_t != MC_OK) return rc_t;
+                q8_ok = os_shift >= 0;
+            }
+        }
+        if (os_shape && os_applies(e, st, count, slice, d_in1, d_in2, d_outL, d_outR, q8_ok, &os_ovl)) {
+            const int rc = run_os(e, st, e->pipe[(e->pipe_head + e->pipe_count) % kPipe], d_in1, d_in2, d_outL, d_outR, T, os_ovl, slot0, slice, first, count, halo,
+                                  &os_da, os_shift);
             if (rc) return rc;
             e->pipe_count++;
             e->batch_seq++;
@@ -1830,7 +1860,7 @@ int run_front(mc_engine* e, const float* d_in1, const float* d_in2, int T, float
                 hipLaunchKernelGGL(da_shift >= 0 ? k_fwd<true> : k_fwd<false>, dim3((hi[r] - lo[r] + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_in1, d_in2, 1,
                                    (int64_t)T * MC_B, T, e->d_fdl, e->ring, slot0, d_ptab, pstride, d_sums, e->d_slotgain, e->d_tw,
                                    e->d_fdl16, e->d_xhist, e->xr, e->d_gring, e->rc, (int64_t)e->t_front, need_a0, need_a1, need_b0,
-                                   hist_from, lo[r], da);
+                                   hist_from, lo[r], da, 0);
     }
     if (e->ktiming && e->kev_n == kEvPool) {
         int rc = drain_kernel_events(e);
@@ -3373,7 +3403,7 @@ int mc_load_ir(mc_engine* e, uint64_t idx, const float* lr, uint64_t frames, uin
     if (er == hipSuccess) {
         hipLaunchKernelGGL(k_fwd<false>, dim3((P + FWD_TILE - 1) / FWD_TILE), dim3(XF_THREADS), 0, e->stream, d_lr, d_lr + 1, 2, (int64_t)n, P,
                            ir.d_H, e->Pstride, 0, (const BlockParams*)nullptr, 0, (float4*)nullptr, (float4*)nullptr, e->d_tw,
-                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0, 0, DropAhead());
+                           (uint2*)nullptr, (float*)nullptr, 0, (float4*)nullptr, 0, (int64_t)0, 0, P, P, 0, 0, DropAhead(), 0);
         er = hipGetLastError();
     }
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);

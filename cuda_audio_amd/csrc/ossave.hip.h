@@ -20,7 +20,7 @@
 //               bin (k1, k2) pairs with (512 - k1, 8191 - k2), i.e. with the COMPLEMENT position of the other row in any
 //               bit-permuted order - and the inverse row transforms, in place
 //   k_os_out    per n2: times exp(+2 pi i n2 k1 / N), inverse 512-point transform over k1, and the output stage of
-//               k_inv_wet<true> (Q1/Q2 window sums, predelay, clamp, dry mix; wet ring for the frames later calls reach)
+//               k_inv_wet<true> (Q1/Q2 window sums, Q8 cut terms, predelay, clamp, dry mix; wet ring for the frames later calls reach)
 // Rows 0 and 256 pair with themselves (os_rows0_body).  T is kept as float4 [256 items][8192] = {row item, row 512 - item}
 // (item 0: rows 0 and 256), so the row pass loads and stores 16 bytes per lane like k_g2_mac's window.
 // The spectra A, B are built per (IR set, gains) by the same passes run on the gain-weighted taps (k_os_ir_mix,
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_os_rows(float4* __restrict__
 // Output pass: inverse column transforms and k_inv_wet<true>'s output stage.  grid = segments x 512, block = 1024.
 // The lane that holds four consecutive wet frames {L = Re, R = Im} of the batch finishes them: Q1/Q2 window sums from the
 // prefix ring (out_window), clamp, dry mix (out_frame), stored at the predelay offset; the frames later calls can reach
-// (blocks < wet_head or >= wet_from) also go to the wet ring.  OutArgs as for k_inv_wet (lin, drop unused: null).
+// (blocks < wet_head or >= wet_from) also go to the wet ring.  OutArgs as for k_inv_wet (lin unused: null; drop != null in the Q8 regime: the cut terms of the batch's output frames).
 // Bounds: wet frames i0 in [base + seg hop, min(base + (seg + 1) hop, wet_end)), wet_end <= n_in; output frames tested against [out_from, out_end) blocks;
 // ring indices masked.
 // ---------------------------------------------------------------------------
@@ -424,11 +424,16 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict_
             out_window(oa, u0, win);
 #endif
             const BlockParams& bp = oa.ptab[(o0 >> 8) * oa.pstride];
+            float4 d01 = make_float4(0.f, 0.f, 0.f, 0.f), d23 = d01;  // the Q8 cut terms of the four frames {L, R}, subtracted before the clamp (as k_inv_wet)
+            if (oa.drop) {
+                const float4* dp = reinterpret_cast<const float4*>(oa.drop + o0);
+                d01 = dp[0], d23 = dp[1];
+            }
             float4 fl, fr;
-            out_frame(false, wl4.x, wr4.x, x1q.x, x2q.x, bp, win, fl.x, fr.x);
-            out_frame(true, wl4.y, wr4.y, x1q.y, x2q.y, bp, win, fl.y, fr.y);
-            out_frame(false, wl4.z, wr4.z, x1q.z, x2q.z, bp, win, fl.z, fr.z);
-            out_frame(true, wl4.w, wr4.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
+            out_frame(false, wl4.x - d01.x, wr4.x - d01.y, x1q.x, x2q.x, bp, win, fl.x, fr.x);
+            out_frame(true, wl4.y - d01.z, wr4.y - d01.w, x1q.y, x2q.y, bp, win, fl.y, fr.y);
+            out_frame(false, wl4.z - d23.x, wr4.z - d23.y, x1q.z, x2q.z, bp, win, fl.z, fr.z);
+            out_frame(true, wl4.w - d23.z, wr4.w - d23.w, x1q.w, x2q.w, bp, win, fl.w, fr.w);
             const int64_t os = o0 - (int64_t)oa.out_blk0 * MC_B;
             *reinterpret_cast<float4*>(oa.outL + os) = fl;
             *reinterpret_cast<float4*>(oa.outR + os) = fr;
@@ -442,7 +447,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict_
                 const float b = k == 0 ? wr4.x : (k == 1 ? wr4.y : (k == 2 ? wr4.z : wr4.w));
                 float fl, fr;
                 out_window(oa, u0 + k, win);
-                out_frame((k & 1) != 0, a, b, oa.in1[o], oa.in2[o], bp, win, fl, fr);
+                const float2 d = oa.drop ? oa.drop[o] : make_float2(0.f, 0.f);
+                out_frame((k & 1) != 0, a - d.x, b - d.y, oa.in1[o], oa.in2[o], bp, win, fl, fr);
                 oa.outL[o - (int64_t)oa.out_blk0 * MC_B] = fl;
                 oa.outR[o - (int64_t)oa.out_blk0 * MC_B] = fr;
             }

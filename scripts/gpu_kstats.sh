@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for v in "$@"; do
   ( if [ "$v" != "default" ]; then if [[ "$v" == *=* ]]; then export "$v"; else export MCCONV_LIB=$PWD/$v; fi; fi
     OUT=$PWD/gpurun_out/ks_$(echo $v | tr '/=' '__'); rm -rf $OUT; mkdir -p $OUT
-    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $OLDPWD/bench.py --steps 20 --warmup 5 --prewarm-ms 100 --no-cpu-baseline --no-latency --no-host-io --no-parity > $OUT/run.log 2>&1)
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $OLDPWD/bench.py --steps 20 --warmup 5 --prewarm-ms 100 --no-cpu-baseline --no-latency --no-host-io --no-parity --no-literal-mac $BENCH_ARGS > $OUT/run.log 2>&1)
     python3 - "$OUT" "$v" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv')[0]

@@ -1930,16 +1930,22 @@ def test_overlap_save_batches_match_the_partitioned_passes(oracle_mod, gpu_lib, 
         assert err <= RMS_TOL, f"blocks [{b0}, {b0 + n}): rms {err:.3e} (signal {rms(want):.3e})"
 
 
-def test_overlap_save_form_keeps_out_of_the_q8_regime_and_of_retired_epochs(gpu_lib, monkeypatch):
-    """The form is for batches whose output is the plain sum over the window plus the Q1/Q2 terms: in the Q8 regime (taps + 255 +
-    predelay > n_ref: cut terms) and while a retired predelay epoch still rings out or lies inside the segments' history the
-    partitioned passes run - and the outputs agree with MCCONV_OS=0 either way."""
+def test_overlap_save_form_in_the_q8_regime_and_around_retired_epochs(gpu_lib, monkeypatch):
+    """The Q8 regime (taps + 255 + predelay > n_ref: the reference cuts what its shift pushes past n_ref) at the SHIPPED shape -
+    settings.txt: fftSize 131072, predelay 1024, an IR of fftSize - 1024 frames on both halves - leaves every output block ONE cut
+    term of ONE source block: the form takes such batches too, the forward transforms of all blocks summing the cut terms
+    (k_fwd<true> with delay-line slots for the batch's tail only, k_drop_fft for the first 516 blocks) and the output pass
+    subtracting them before the clamp.  Other Q8 shapes (here: predelay 2000, three partitions cut), the batch in which a predelay epoch is
+    retired, and batches whose history reaches into the retired epoch run the partitioned passes (scripts/probes/os_q8_oracle.py holds
+    the form in this regime to oracle.RefCompat directly: 1.1e-8 RMS at n_ref 16384).  Everything against MCCONV_OS=0,
+    which the Q8 tests hold to oracle.RefCompat."""
     import torch
 
     from cuda_audio_amd.synth import make_input, make_ir
 
     n_ref, T = 131072, 13000
-    x = make_input(5 * T * 256)
+    nbat = 7
+    x = make_input(nbat * T * 256)
     irs = [make_ir(130048, seed=7, norm=0.02), make_ir(100000, seed=8, norm=0.02)]
 
     def run(os_on):
@@ -1950,11 +1956,14 @@ def test_overlap_save_form_keeps_out_of_the_q8_regime_and_of_retired_epochs(gpu_
         apply_params(c, dict(BASE, predelay=1024), dict(BASE, select=0, predelay=1024), False)  # the shipped shape: Q8 regime
         dev = torch.device("cuda:0")
         d_in = torch.from_numpy(x).to(dev)
-        d_out = torch.zeros(2, 5 * T * 256, device=dev)
+        d_out = torch.zeros(2, nbat * T * 256, device=dev)
         c.enable_kernel_timing(True)
         lv = []
-        for k in range(5):
-            if k == 2:  # the shorter IR on both halves, no predelay: out of the regime, but the old epoch rings out / lies in the history
+        for k in range(nbat):
+            if k == 3:  # a longer, unaligned predelay: several partitions' segments are cut - not the one-term shape
+                c.cc[0].value.update(predelay=2000)
+                c.cc[1].value.update(predelay=2000)
+            if k == 5:  # the shorter IR on both halves, no predelay: out of the regime
                 c.cc[0].value.update(select=1, predelay=0, vsteps=0)
                 c.cc[1].value.update(select=1, predelay=0, vsteps=0)
             o = k * T * 256
@@ -1962,17 +1971,22 @@ def test_overlap_save_form_keeps_out_of_the_q8_regime_and_of_retired_epochs(gpu_
             c.sync()
             lv.append(c.kernel_stats()["fast_levels"])
         out = d_out.cpu().numpy()
+        st = c.drop_stats()
         c.close()
-        return out, lv
+        return out, lv, st
 
-    ref, lv0 = run(False)
-    got, lv1 = run(True)
+    ref, lv0, st0 = run(False)
+    got, lv1, st1 = run(True)
     assert 253 not in lv0
-    assert lv1[0] != 253 and lv1[1] != 253 and lv1[2] != 253, lv1  # Q8 regime; then the batch of the change
-    assert lv1[4] == 253, lv1  # two batches later the window is settled and the old epoch out of reach
-    for k in range(5):
+    assert lv1[0] != 253 and lv1[1] == 253 and lv1[2] == 253, lv1  # cold-start ramp, then the shipped shape in the form
+    assert 253 not in lv1[3:6], lv1  # the predelay change and the unaligned Q8 shape; then the change out of the regime
+    assert lv1[6] == 253, lv1  # the window is settled again and the old epochs are out of reach
+    assert st1["forward_transforms"] >= 2, st1
+    for k in range(nbat):
         d = rms(got[:, k * T * 256:(k + 1) * T * 256] - ref[:, k * T * 256:(k + 1) * T * 256])
         assert d <= 1e-6, f"batch {k}: {d:.3e}"
+    # the cut terms are there: the same stream as a plain linear convolution differs in the regime's batches
+    assert rms(ref[:, T * 256:2 * T * 256]) > 0.01
 
 
 @pytest.mark.parametrize("pd", [0, 1024, 301])
