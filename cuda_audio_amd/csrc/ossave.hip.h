@@ -238,10 +238,13 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_os_rows(float4* __restrict__
     // items 8 apart in launch order share an XCD: an item's segments follow each other there (its spectra are read into that L2 once)
     const int xq = (int)blockIdx.x >> 3;
     const int item = (xq / nseg) * 8 + ((int)blockIdx.x & 7), seg = xq % nseg;
-    if (nseg * OS_ITEMS >= 2048) {  // issue priority for one of a CU's two workgroups (k_g2_mac, G2_PRIO)
+#ifndef OS_PRIO
+#define OS_PRIO 3
+#endif
+    if (OS_PRIO && nseg * OS_ITEMS >= 2048) {  // issue priority for one of a CU's two workgroups (k_g2_mac, G2_PRIO)
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if ((hwid & 0xfu) >= 2u) __builtin_amdgcn_s_setprio(3);
+        if ((hwid & 0xfu) >= 2u) __builtin_amdgcn_s_setprio(OS_PRIO);
     }
     g2_tables(t_lo, t_hi);
     __syncthreads();

@@ -7,7 +7,10 @@ forward transforms sum them where the shape allows) and single periods.  usage: 
 `jack`: single 256-frame periods only, 1200 of them, controller events 40-250 calls apart: the parked path (and, in the Q8 regime, the cut terms
 carried by the launch before) under parameter changes.
 `long`: `general` with batches of up to 1500 calls and the switch-over to the second-level transform lowered (MCCONV_FFT2_WORK=1, set here): the
-kernels of the headline (k_g2_mac; k_f2_* where gains differ per block and the IRs have >= 256 partitions: every fifth run is at n_ref = 131072)."""
+kernels of the headline (k_g2_mac; k_f2_* where gains differ per block and the IRs have >= 256 partitions: every fifth run is at n_ref = 131072).
+`os` (round 4): `long` on the LAB build (MCCONV_LIB=build_ab/lib_lab.so) with the overlap-save form taken from 48 blocks on (MCCONV_OS_MIN=48, set here; the
+product takes it from 12288): every settled batch of a random stream runs as one 512 x 8192-frame segment - any IR set, predelay, period size, the Q8
+regime's one-term shape through the forward transforms - between batches and periods of every other form."""
 import ctypes as C
 import os
 import sys
@@ -23,18 +26,21 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
+os_mode = len(sys.argv) > 3 and sys.argv[3] == "os"
+long_ = os_mode or (len(sys.argv) > 3 and sys.argv[3] == "long")
 jack = len(sys.argv) > 3 and sys.argv[3].startswith("jack")  # (jack512 / jack1024: periods of that many frames)  # single periods only, events far enough apart that the periods in between are parked one call ahead
 general = long_ or (len(sys.argv) > 3 and sys.argv[3] == "general")
 if long_:
     os.environ["MCCONV_FFT2_WORK"] = "1"
+if os_mode:
+    os.environ["MCCONV_OS_MIN"] = "48"
 BMAX = 1500 if long_ else 64  # calls per batch
 trace = os.environ.get("FUZZ_TRACE") == "1"  # every call printed before it runs and synchronised after it (fault triage)
 TOL = 1e-5
 cmap = (21, 22, 23, 24, 25, 26, 27, 28)
 arr = (C.c_uint8 * 8)(*cmap)
 bad = 0
-tot = dict(drop_fft=0, forward_transforms=0, tiles=0, carried_periods=0, fused=0, split=0, resident=0)
+tot = dict(drop_fft=0, forward_transforms=0, tiles=0, carried_periods=0, fused=0, split=0, resident=0, batches=0, spectra_builds=0)
 for seed in range(first, first + runs):
     rng = np.random.default_rng(seed)
     n_ref = int(rng.choice([4096, 8192, 16384] if general else [4096, 8192]))
@@ -106,6 +112,9 @@ for seed in range(first, first + runs):
     try:
         st = c.drop_stats()
         st.update(c.mac_stats())
+        st.update(c.os_stats())  # (overlap-save form: batches that took it, builds of its spectra)
+        if os_mode and not c.lab_build():
+            raise SystemExit("the os mode needs the lab build: MCCONV_LIB=build_ab/lib_lab.so")
     except Exception:  # (the single-transform form, MCCONV_FORM=single, keeps no such counters)
         st = {}
     c.close()

@@ -14,6 +14,12 @@ from helpers import BASE, RMS_TOL, apply_params, rms
 pytestmark = pytest.mark.gpu
 
 
+def _os_form_possible():
+    """The overlap-save form needs the output finished by the transform kernels: the lab build's MCCONV_INV_WET=0 / MCCONV_FUSE_OUT=0
+    (the suite is also run under those) send it elsewhere, and with the cut terms' alternatives switched off the Q8 shape stays out."""
+    return not any(os.environ.get(k) == "0" for k in ("MCCONV_INV_WET", "MCCONV_FUSE_OUT"))
+
+
 def _conv(**kw):
     from cuda_audio_amd.engine import Convolution
 
@@ -885,7 +891,7 @@ def test_config5_fp16_full_length_30s(gpu_lib):
     c.close()
 
 
-def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib):
+def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib, monkeypatch):
     """mc_config.precision = 1 keeps IR spectra and delay line in fp16 for the partition sweep (single periods, short batches).
     A long settled batch runs as overlap-save segments in either precision - the form's spectra are built from the fp32 taps - so an
     fp16 engine's long batches are the fp32 engine's (1e-6), and the periods that follow go back to the fp16 sweep on the
@@ -894,6 +900,7 @@ def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib):
 
     from cuda_audio_amd.synth import make_input, make_ir
 
+    monkeypatch.setenv("MCCONV_OS", "1")  # (the suite is also run with the measurement switches set)
     n_ref, taps, T = 131072, 88200, 13000
     x = make_input((3 * T + 4) * 256)
     ir = make_ir(taps, seed=5678)
@@ -915,7 +922,8 @@ def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib):
         a = 3 * T * 256
         per.append(np.concatenate([np.stack(c.onProcess(x[0, a + 256 * j:a + 256 * (j + 1)], x[1, a + 256 * j:a + 256 * (j + 1)])) for j in range(4)], axis=1))
         c.close()
-    assert levels[0][1:] == [253, 253] and levels[1][1:] == [253, 253], levels
+    if _os_form_possible():
+        assert levels[0][1:] == [253, 253] and levels[1][1:] == [253, 253], levels
     assert rms(outs[1][1:] - outs[0][1:]) <= 1e-6
     wet = rms(per[0]) * 0.5
     assert rms(per[1] - per[0]) <= FP16_REL_TOL * wet + 1e-6
@@ -1820,7 +1828,8 @@ def test_headline_launch_against_the_range_oracle(oracle_mod, gpu_lib, monkeypat
         assert T == ((129296 if at_most > 32768 else 32320) if taps == 441000 else (30248 if level == 254 else 22432))
         chunk = (8192 if level == 254 else 16384) - p16 + 1
         assert T == (-(-T // chunk) * chunk - 1) // 8 * 8  # whole chunks minus the halo block, rounded down to 8
-    assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
+    if level != 253 or _os_form_possible():
+        assert levels[1] == level and levels[2] == level, levels  # steady state: one set of gains over the window
     ranges = [(T + 100, 256), (T + chunk - 65, 130), (2 * T - 128, 128 + 64)]  # (first block, blocks) in the stream
     num = den = 0.0
     for b0, n in ranges:
@@ -1906,16 +1915,18 @@ def test_overlap_save_batches_match_the_partitioned_passes(oracle_mod, gpu_lib, 
     ref, lv0, st0 = run(False)
     got, lv1, st1 = run(True)
     assert st0["batches"] == 0 and 253 not in lv0
-    # batches 1-4 and 6 (one set of gains), 8 and 9 after the cross-fade has settled within the window or not: at least these
-    assert [lv1[k] for k in (1, 2, 3, 4, 6)] == [253] * 5, lv1
     assert lv1[0] != 253 and lv1[5] != 253 and lv1[7] != 253, lv1  # cold-start ramp, gain change, cross-fade: per-slot gains
-    assert st1["batches"] >= 5 and st1["spectra_builds"] >= 2
+    if _os_form_possible():
+        # batches 1-4 and 6 (one set of gains), 8 and 9 after the cross-fade has settled within the window or not: at least these
+        assert [lv1[k] for k in (1, 2, 3, 4, 6)] == [253] * 5, lv1
+        assert st1["batches"] >= 5 and st1["spectra_builds"] >= 2
     o = 0
     for k, n in enumerate(sizes + [nper]):
         d = rms(got[:, o * 256:(o + n) * 256] - ref[:, o * 256:(o + n) * 256])
         assert d <= 1e-6, f"batch {k} ({n} blocks, form {lv1[k] if k < len(lv1) else 'periods'}): {d:.3e} from the partitioned passes"
         o += n
-    assert rms(got - ref) > 0
+    if _os_form_possible():
+        assert rms(got - ref) > 0
     # steady stretches against the oracle itself: inside batch 2's second segment, the end of batch 3 and the start of batch 4
     s1, s3 = sum(sizes[:2]), sum(sizes[:4])
     for b0, n in [(s1 + hop - 40, 120), (s3 - 70, 140)]:
@@ -1978,10 +1989,12 @@ def test_overlap_save_form_in_the_q8_regime_and_around_retired_epochs(gpu_lib, m
     ref, lv0, st0 = run(False)
     got, lv1, st1 = run(True)
     assert 253 not in lv0
-    assert lv1[0] != 253 and lv1[1] == 253 and lv1[2] == 253, lv1  # cold-start ramp, then the shipped shape in the form
-    assert 253 not in lv1[3:6], lv1  # the predelay change and the unaligned Q8 shape; then the change out of the regime
-    assert lv1[6] == 253, lv1  # the window is settled again and the old epochs are out of reach
-    assert st1["forward_transforms"] >= 2, st1
+    assert lv1[0] != 253 and 253 not in lv1[3:6], lv1  # cold-start ramp; the predelay change and the three-partition Q8 shape; the change out of the regime
+    if _os_form_possible() and not any(os.environ.get(k) == "0" for k in ("MCCONV_FUSE_DROP", "MCCONV_DROP_AHEAD", "MCCONV_TD_FFT")):
+        assert lv1[1] == 253 and lv1[2] == 253, lv1  # the shipped shape in the form
+        assert st1["forward_transforms"] >= 2, st1
+    if _os_form_possible():
+        assert lv1[6] == 253, lv1  # the window is settled again and the old epochs are out of reach
     for k in range(nbat):
         d = rms(got[:, k * T * 256:(k + 1) * T * 256] - ref[:, k * T * 256:(k + 1) * T * 256])
         assert d <= 1e-6, f"batch {k}: {d:.3e}"
@@ -2042,8 +2055,10 @@ def test_overlap_save_form_of_block_slices(oracle_mod, gpu_lib, monkeypatch, pd)
     for c in ranks + [whole]:
         c.close()
     ref, got = ref.cpu().numpy(), got.cpu().numpy()
-    assert 253 not in levels[:2] and levels[2:] == [253] * (2 * nbat - 2), levels  # (the first batch's window holds the cold-start ramp)
-    assert st == [nbat - 1] * world, st
+    assert 253 not in levels[:2], levels  # (the first batch's window holds the cold-start ramp)
+    if _os_form_possible():
+        assert levels[2:] == [253] * (2 * nbat - 2), levels
+        assert st == [nbat - 1] * world, st
     for k in range(nbat):
         d = rms(got[:, k * T * 256:(k + 1) * T * 256] - ref[:, k * T * 256:(k + 1) * T * 256])
         assert d <= 1e-6, f"batch {k}: {d:.3e} from the unsliced partitioned passes"
