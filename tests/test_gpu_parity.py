@@ -924,8 +924,9 @@ def test_fp16_engines_take_the_overlap_save_form_for_long_batches(gpu_lib, monke
         c.close()
     if _os_form_possible():
         assert levels[0][1:] == [253, 253] and levels[1][1:] == [253, 253], levels
-    assert rms(outs[1][1:] - outs[0][1:]) <= 1e-6
     wet = rms(per[0]) * 0.5
+    # (where a lab switch keeps the form away, the fp16 engine's long batches are the fp16 sweep's)
+    assert rms(outs[1][1:] - outs[0][1:]) <= (1e-6 if _os_form_possible() else FP16_REL_TOL * wet + 1e-6)
     assert rms(per[1] - per[0]) <= FP16_REL_TOL * wet + 1e-6
 
 
@@ -2115,8 +2116,10 @@ def test_native_group_driver(oracle_mod, gpu_lib, ranks):
         o += n
     c.close()
     g.close()
-    if ranks == 1:  # (one rank sums all partitions in the plain engine's order: the same bits, with or without the exchange)
+    if ranks == 1 and not os.environ.get("MCCONV_LIB"):  # (one rank sums all partitions in the plain engine's order: the same bits, with or without the exchange)
         assert np.array_equal(got, ref)
+    elif ranks == 1:  # (MCCONV_LIB swaps the library of the plain engine only: libmcconv_rccl.so links the default build)
+        assert rms(got - ref) <= 1e-6
     else:
         assert 0 < rms(got - ref) <= 1e-6, rms(got - ref)
     nchk = 1200
