@@ -362,7 +362,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_os_rows(float4* __restrict__
 // Bounds: wet frames i0 in [base + seg hop, min(base + (seg + 1) hop, wet_end)), wet_end <= n_in; output frames tested against [out_from, out_end) blocks;
 // ring indices masked.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict__ Tbuf, OsGeo G, float* __restrict__ wet, int wr,
+__global__ __launch_bounds__(OS_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_os_out(const float4* __restrict__ Tbuf, OsGeo G, float* __restrict__ wet, int wr,
                                                        const float2* __restrict__ g_tw, OutArgs oa) {
     __shared__ float2 s_tw[FFT_N];
     __shared__ __align__(16) float2 s_mem[OS_TILE * OS_WSTR];
@@ -398,7 +398,11 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_out(const float4* __restrict_
     fft512_wave<+1, false>(v, s_mem + wave * OS_WSTR, s_tw, lane);
 #endif
     __syncthreads();
+#ifdef OS_OUT_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int it = 0; it < 2; it++) {
         const int e = tid + OS_THREADS * it, n1 = e >> 2, q = e & 3;
         const int64_t n = (int64_t)OS_N2 * n1 + n2_0 + 4 * q;

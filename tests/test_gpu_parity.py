@@ -1991,7 +1991,7 @@ def test_overlap_save_form_in_the_q8_regime_and_around_retired_epochs(gpu_lib, m
     got, lv1, st1 = run(True)
     assert 253 not in lv0
     assert lv1[0] != 253 and 253 not in lv1[3:6], lv1  # cold-start ramp; the predelay change and the three-partition Q8 shape; the change out of the regime
-    if _os_form_possible() and not any(os.environ.get(k) == "0" for k in ("MCCONV_FUSE_DROP", "MCCONV_DROP_AHEAD", "MCCONV_TD_FFT")):
+    if _os_form_possible() and not any(os.environ.get(k) == "0" for k in ("MCCONV_FUSE_DROP", "MCCONV_DROP_AHEAD", "MCCONV_TD_FFT", "MCCONV_HTAIL")):
         assert lv1[1] == 253 and lv1[2] == 253, lv1  # the shipped shape in the form
         assert st1["forward_transforms"] >= 2, st1
     if _os_form_possible():
