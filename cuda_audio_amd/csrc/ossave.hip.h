@@ -239,7 +239,7 @@ __global__ __launch_bounds__(G2B_THREADS, 4) void k_os_rows(float4* __restrict__
     const int xq = (int)blockIdx.x >> 3;
     const int item = (xq / nseg) * 8 + ((int)blockIdx.x & 7), seg = xq % nseg;
 #ifndef OS_PRIO
-#define OS_PRIO 3
+#define OS_PRIO 0
 #endif
     if (OS_PRIO && nseg * OS_ITEMS >= 2048) {  // issue priority for one of a CU's two workgroups (k_g2_mac, G2_PRIO)
         unsigned hwid;
