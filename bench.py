@@ -1221,7 +1221,7 @@ def main():
             tr = labelled_profile("r4_hbm_traffic.json", "headline")
             traffic = None
             if tr:
-                rec = [v for k, v in tr["data"].items() if "k_os_rows" in k]
+                rec = [v for k, v in tr["data"].items() if k.split("(")[0].strip() == "k_os_rows"]
                 tr["data"] = rec
                 if rec and all(int(v.get("blocks_per_launch", -1)) == int(blk) for v in rec):
                     traffic = sum(int(v["hbm_bytes_per_launch"]) for v in rec)
