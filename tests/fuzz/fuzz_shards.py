@@ -3,7 +3,9 @@
 Every run picks a layout - partition shards finished on rank 0 (`reduce`), partition shards with every rank finishing its run of
 blocks (`reduce_scatter`), or output blocks sliced across ranks with no exchange (`slices`) - a world of 2..4 ranks, IR lengths up
 to n_ref - 1024, a period of 256 / 512 frames, batches of random length, and controller traffic between batches (select, predelay,
-wet, speed, pans, level).  usage: fuzz_shards.py [first_seed] [runs]"""
+wet, speed, pans, level).  usage: fuzz_shards.py [first_seed] [runs] [os]
+`os` (round 4, lab build: MCCONV_LIB=build_ab/lib_lab.so): the overlap-save form from one block on (MCCONV_OS_MIN=1), so that the block slices of
+every settled batch run as a segment that reads its history from the batch in front of the slice."""
 import ctypes as C
 import os
 import sys
@@ -20,6 +22,9 @@ from cuda_audio_amd.synth import make_input  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+if len(sys.argv) > 3 and sys.argv[3] == "os":
+    os.environ["MCCONV_OS_MIN"] = "1"
+os_batches = 0
 TOL = 1e-5
 cmap = (21, 22, 23, 24, 25, 26, 27, 28)
 arr = (C.c_uint8 * 8)(*cmap)
@@ -132,10 +137,11 @@ for seed in range(first, first + runs):
     torch.cuda.synchronize()
     err = float(np.sqrt(np.mean((got.cpu().numpy()[:, :q * period] - want[:, :q * period]) ** 2))) if q else 0.0
     for e in eng:
+        os_batches += e.os_stats()["batches"]
         e.close()
     count[layout] = count.get(layout, 0) + 1
     flag = "" if err <= TOL else "   <-- FAIL"
     bad += err > TOL
     print(f"seed {seed}: {layout} x{world}, n_ref {n_ref}, period {period}, IRs {lens}, rms {err:.3e} (signal {np.sqrt(np.mean(want[:, :max(q, 1) * period] ** 2)):.3e}){note}{flag}", flush=True)
-print(f"{runs} runs {count}, {bad} above {TOL}")
+print(f"{runs} runs {count}, {bad} above {TOL}; rank-batches in the overlap-save form: {os_batches}")
 sys.exit(1 if bad else 0)
