@@ -297,7 +297,7 @@ struct mc_engine {
     uint64_t n_mac_form[3] = {0, 0, 0};  // batches whose partition sums took the fused / split second-level transform / the resident MAC (mc_debug_read item 10)
     uint64_t n_drop_fft = 0, n_drop_ahead = 0, n_drop_tiles = 0;  // Q8 regime: batches by the form their cut terms took (mc_debug_read item 9)
 #ifdef MC_JACK_TRACE
-    double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0;
+    double tr_launch = 0, tr_flag = 0, tr_total = 0, tr_kernel = 0, tr_gap = 0, tr_out = 0, tr_clk = 0, tr_c[3] = {0, 0, 0};
     unsigned long long tr_prev_end = 0;
     long tr_n = 0;
 #endif
@@ -2573,6 +2573,9 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             e->tr_flag += std::chrono::duration<double, std::micro>(tr2 - tr0).count();
             e->tr_total += std::chrono::duration<double, std::micro>(tr3 - tr0).count();
             e->tr_kernel += (double)(w[2] - w[1]) * 0.01;
+            e->tr_out += (double)(w[3] - w[1]) * 0.01;
+            e->tr_clk += (double)w[4];
+            for (int i = 0; i < 3; i++) e->tr_c[i] += (double)w[5 + i];
             if (e->tr_prev_end) e->tr_gap += (double)(w[1] - e->tr_prev_end) * 0.01;
         }
         e->tr_prev_end = w[2];
@@ -3265,8 +3268,8 @@ void mc_destroy(mc_engine* e) {
 #ifdef MC_JACK_TRACE
     if (e->tr_n > 100) {
         const double n = (double)(e->tr_n - 100);
-        fprintf(stderr, "mcconv JACK trace over %ld periods (us): entry -> launches issued %.2f, -> flag seen %.2f, -> return %.2f; k_tail1 start -> end %.2f, "
-                        "end of the previous k_tail1 -> start of this one %.2f\n", e->tr_n - 100, e->tr_launch / n, e->tr_flag / n, e->tr_total / n, e->tr_kernel / n, e->tr_gap / n);
+        fprintf(stderr, "mcconv JACK trace over %ld periods (us): entry -> launches issued %.2f, -> flag seen %.2f, -> return %.2f; k_tail1 start -> output issued %.2f (%.0f shader clocks; first barrier %.0f, sums done %.0f, second barrier %.0f), -> end %.2f, "
+                        "end of the previous k_tail1 -> start of this one %.2f\n", e->tr_n - 100, e->tr_launch / n, e->tr_flag / n, e->tr_total / n, e->tr_out / n, e->tr_clk / n, e->tr_c[0] / n, e->tr_c[1] / n, e->tr_c[2] / n, e->tr_kernel / n, e->tr_gap / n);
     }
 #endif
     (void)hipSetDevice(e->device);

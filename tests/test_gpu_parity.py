@@ -2422,7 +2422,9 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
     finds that the parked tail gave up on its own and launches the period again - the kernel queued behind it has
     meanwhile swept into this period's partial sums, which are summed again (round-2 advice: process_one did not);
     a controller change, a batch call and an IR reload tell the parked period to give up; the samples are the oracle's
-    throughout.  MCCONV_NO_PARK=1 (every period launched on arrival) gives the same bits."""
+    throughout.  MCCONV_NO_PARK=1 (every period launched on arrival) gives the same samples to rounding: since round 4 a
+    256-frame period that has to be waited for takes partition 0 in the time domain, one that is already there in the frequency
+    domain (kernels.hip.h, tail1_body); the 512-frame path has one form and gives the same bits."""
     import time
 
     from cuda_audio_amd.synth import make_input, make_ir
@@ -2513,7 +2515,10 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
             assert stats["end"] == dict(used=0, timed_out=0, cancelled=0), stats
         err = rms(outs[-1] - want)
         assert err <= RMS_TOL, f"park={park}: rms {err:.3e}"
-    assert np.array_equal(outs[0], outs[1])
+    if period == 256 and not os.environ.get("MCCONV_LIB"):  # (a lab build may carry the one-form tail)
+        assert np.abs(outs[0] - outs[1]).max() <= 5e-7, np.abs(outs[0] - outs[1]).max()
+    else:
+        assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("predelay", [0, 64, 300, 301, 2047, 8192])
