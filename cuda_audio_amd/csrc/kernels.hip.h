@@ -2421,11 +2421,13 @@ __device__ __forceinline__ void td_taps(const float4* s_hc, int c, bool on, v2f 
 }
 // the unit's 8 partial sums {L, R}: xpad = the (possibly reversed) period with TD_PAD zeros in front
 template <int NT>
-__device__ __forceinline__ void td_tile(const float2* xpad, int a, int c, const v2f (&h1)[NT], const v2f (&h2)[NT], v2f (&acc)[8]) {
+__device__ __forceinline__ void td_window(const float2* xpad, int a, int c, v2f (&w)[NT + 7]) {
     const float2* w0 = xpad + TD_PAD + 8 * a - NT * c - (NT - 1);  // frame of window entry 0 (>= -TD_PAD)
-    v2f w[NT + 7];
 #pragma unroll
-    for (int q = 0; q < NT + 7; q++) w[q] = vx_of(w0[q]);
+    for (int q = NT + 6; q >= 0; q--) w[q] = vx_of(w0[q]);  // (in the order of use: tap 0 takes the last eight entries)
+}
+template <int NT>
+__device__ __forceinline__ void td_tile(const v2f (&w)[NT + 7], const v2f (&h1)[NT], const v2f (&h2)[NT], v2f (&acc)[8]) {
 #pragma unroll
     for (int o = 0; o < 8; o++) acc[o] = v2f{0.f, 0.f};
 #pragma unroll
@@ -2896,30 +2898,63 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         const bool live = pass == 1;
         if (live) {
             if (A.in_gran) {
-                // Parked, tagged input: every lane polls its own two granules of the period; wave 0 also watches the doorbell word for
-                // the "give up" command and the park time.  A wave leaves the loop when all its lanes hold this period's samples, or
-                // when wave 0 has said to leave (an LDS word); the barrier behind the loop makes the decision the workgroup's.
+                // Parked, tagged input: every lane looks at its own two granules of the period; lane 0 also watches the doorbell word for
+                // the "give up" command and the park time.  THREE looks are in flight, a third of a round trip through memory apart
+                // (a look whose request passes the memory side before the period lands comes back empty: with one look at a time
+                // the period is seen half a round trip + half a look-to-look distance after it lands, 0.7 us; with three, 0.45).
+                // A wave leaves the loop when all its lanes hold this period's samples, or when wave 0 has said to leave (an LDS
+                // word); the barrier behind the loop makes the decision the workgroup's.
+                const unsigned long long* q1 = A.in_gran + tid;
+                const unsigned long long* q2 = A.in_gran + MC_B + tid;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    const unsigned long long g1 = __hip_atomic_load(A.in_gran + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    const unsigned long long g2 = __hip_atomic_load(A.in_gran + MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (__all((unsigned)(g1 >> 32) == seq && (unsigned)(g2 >> 32) == seq)) {
-                        xin1 = __uint_as_float((unsigned)g1);
-                        xin2 = __uint_as_float((unsigned)g2);
-                        break;
-                    }
-                    if (tid == 0) {
-                        const unsigned long long v = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if ((unsigned)v == seq && (v >> 32) != 0) {
-                            *(volatile int*)&s_abort = 1;  // told to give up
-                        } else if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {
-                            __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            *(volatile int*)&s_abort = 1;  // the host has been away for longer than the park time
-                        }
-                    }
-                    if (*(volatile int*)&s_abort) break;
-                    __builtin_amdgcn_s_sleep(2);
+                unsigned long long g1[3], g2[3], gb = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    g1[k] = __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    g2[k] = __hip_atomic_load(q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (k == 0 && tid == 0) gb = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __builtin_amdgcn_s_sleep(8);
                 }
+#define TD_LOOK_HIT(k) __all((unsigned)(g1[k] >> 32) == seq && (unsigned)(g2[k] >> 32) == seq)
+#define TD_LOOK_TAKE(k) xin1 = __uint_as_float((unsigned)g1[k]), xin2 = __uint_as_float((unsigned)g2[k])
+#define TD_LOOK_AGAIN(k) \
+    g1[k] = __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), g2[k] = __hip_atomic_load(q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                // (six rounds per trip of the loop: at the loop's head the compiler waits for everything in flight)
+                for (;;) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        if (TD_LOOK_HIT(0)) {
+                            TD_LOOK_TAKE(0);
+                            goto td_period_seen;
+                        }
+                        TD_LOOK_AGAIN(0);
+                        if (tid == 0) {
+                            if ((unsigned)gb == seq && (gb >> 32) != 0) {
+                                s_abort = 1;  // told to give up
+                            } else if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {
+                                __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                s_abort = 1;  // the host has been away for longer than the park time
+                            }
+                            gb = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        asm volatile("" ::: "memory");  // (the word is read from LDS every time; not through a generic pointer: a flat load would wait for the looks in flight)
+                        if (s_abort) goto td_period_seen;
+                        if (TD_LOOK_HIT(1)) {
+                            TD_LOOK_TAKE(1);
+                            goto td_period_seen;
+                        }
+                        TD_LOOK_AGAIN(1);
+                        if (TD_LOOK_HIT(2)) {
+                            TD_LOOK_TAKE(2);
+                            goto td_period_seen;
+                        }
+                        TD_LOOK_AGAIN(2);
+                    }
+                }
+            td_period_seen:;
+#undef TD_LOOK_HIT
+#undef TD_LOOK_TAKE
+#undef TD_LOOK_AGAIN
                 // (no barrier here: a wave that holds its samples stores them and meets the others at the barrier below; s_abort is
                 // final for a wave only behind that barrier)
             } else {
@@ -2969,8 +3004,16 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         c_fma = 0;
 #endif
         {
-            v2f acc[8];
-            td_tile<TD_NT1>(s_xp, uon ? ua : 0, uon ? uc : 0, h1r, h2r, acc);
+            v2f acc[8], win[TD_NT1 + 7];
+            td_window<TD_NT1>(s_xp, uon ? ua : 0, uon ? uc : 0, win);
+            // the block's sums {S1, S2, A1, A2} (conv.cu:55-71: what the DC / Nyquist bins of its transform hold), per wave, while
+            // the window is on its way from LDS
+            {
+                const float sg = (tid & 1) ? -1.f : 1.f;
+                const float r0 = td_wave_sum(xin1), r1 = td_wave_sum(xin2), r2 = td_wave_sum(sg * xin1), r3 = td_wave_sum(sg * xin2);
+                if (lane == 0) s_red[wave] = make_float4(r0, r1, r2, r3);
+            }
+            td_tile<TD_NT1>(win, h1r, h2r, acc);
 #ifdef MC_JACK_TRACE
             asm volatile("" ::"v"(acc[0]), "v"(acc[7]));
             c_fma = __builtin_amdgcn_s_memtime();
@@ -2980,11 +3023,6 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
 #pragma unroll
                 for (int o = 0; o < 4; o++) dst[o] = make_float4(acc[2 * o].x, acc[2 * o].y, acc[2 * o + 1].x, acc[2 * o + 1].y);
             }
-        }
-        {  // the block's sums {S1, S2, A1, A2} (conv.cu:55-71: what the DC / Nyquist bins of its transform hold), per wave
-            const float sg = (tid & 1) ? -1.f : 1.f;
-            const float r0 = td_wave_sum(xin1), r1 = td_wave_sum(xin2), r2 = td_wave_sum(sg * xin1), r3 = td_wave_sum(sg * xin2);
-            if (lane == 0) s_red[wave] = make_float4(r0, r1, r2, r3);
         }
         __syncthreads();
 #ifdef MC_JACK_TRACE
@@ -3042,6 +3080,9 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
             const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
             const float yl = vl + x1 * dmix.x + x2 * dmix.y, yr = vr + x1 * dmix.z + x2 * dmix.w;
+#ifdef MC_JACK_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_out) : "v"(yl), "v"(yr));  // (the output is ready to be stored)
+#endif
             if (!live) {
                 asm volatile("" ::"v"(yl), "v"(yr));  // (the dry run: computed, not stored)
             } else if (A.out_gran) {  // the output as granules {value, sequence number}: on the host as soon as the posted writes land
@@ -3054,7 +3095,6 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         }
 #ifdef MC_JACK_TRACE
         t_out = __builtin_amdgcn_s_memrealtime();  // the output's stores are issued
-        c_out = __builtin_amdgcn_s_memtime();      // (shader clocks over the same stretch)
 #endif
     }
     write_history(td, tau, tabs0, m, xin1, xin2, bp, rc);
@@ -3088,9 +3128,10 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     } else {
         int a2, c2;
         const bool on2 = td_unit<TD_NT2>(tid - 64, a2, c2);
-        v2f g1[TD_NT2], g2[TD_NT2], acc[8];
+        v2f g1[TD_NT2], g2[TD_NT2], acc[8], win[TD_NT2 + 7];
         td_taps<TD_NT2, true>(s_hc, c2, on2, g1, g2);
-        td_tile<TD_NT2>(s_xr, on2 ? a2 : 0, on2 ? c2 : 0, g1, g2, acc);
+        td_window<TD_NT2>(s_xr, on2 ? a2 : 0, on2 ? c2 : 0, win);
+        td_tile<TD_NT2>(win, g1, g2, acc);
         if (on2) {
             float4* dst = reinterpret_cast<float4*>(&s_pc[c2][8 * a2]);
 #pragma unroll
