@@ -2386,26 +2386,28 @@ struct TailArgs {
 // frequency domain, inverse transform - all behind the arrival.
 //
 // The direct convolution, register-tiled (a thread per output frame and tap reads 24 bytes of LDS per four multiply-adds: 3 us):
-// a unit is 8 consecutive output frames x NT consecutive taps; the taps {L<-in1, R<-in1, L<-in2, R<-in2} sit in registers before
-// the period arrives, the unit's NT + 7 input frames come from LDS (zeros in front of the period take care of the triangle), each
-// (frame, tap) is two packed multiply-adds (v_pk_fma_f32 with the input sample broadcast), and the partial sums of the units of a
-// frame meet in LDS in a fixed order.  First half of the segment (frames 0..255: taps j <= m): NT = 18, 249 units on 256 threads,
-// 288 packed instructions each.  Second half (frames 256 + r: taps j > r), behind the output: the same triangle with both
-// sequences reversed, NT = 24, 187 units on waves 1-3 while wave 0 transforms the period for the delay line.
+// a unit is NO consecutive output frames x NT consecutive taps; the taps {L<-in1, R<-in1, L<-in2, R<-in2} sit in registers before
+// the period arrives, the unit's NT + NO - 1 input frames come from LDS (zeros in front of the period take care of the triangle),
+// each (frame, tap) is two packed multiply-adds (v_pk_fma_f32 with the input sample broadcast), and the partial sums of the units
+// of a frame meet in LDS in a fixed order.  One wavefront issues a packed multiply-add every 4.8 clocks however many share its
+// SIMD (scripts/probes/pkfma_probe.hip), so the workgroup has EIGHT wavefronts: threads 256..511 (tail1_helper) only convolve.
+// First half of the segment (frames 0..255: taps j <= m): 4 frames x 18 taps, 491 units on 512 threads, 144 packed instructions
+// each.  Second half (frames 256 + r: taps j > r), behind the output: the same triangle with both sequences reversed, 8 frames x
+// 18 taps, 249 units on the helper threads while wave 0 transforms the period for the delay line.
 // ---------------------------------------------------------------------------
 #define TD_PAD 32  // zeros in front of the period in LDS (a unit's window starts up to NT + 6 frames before frame 0)
 __device__ __forceinline__ void td_fma_in1(v2f& acc, v2f h, v2f x) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(h), "v"(x)); }
 __device__ __forceinline__ void td_fma_in2(v2f& acc, v2f h, v2f x) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(h), "v"(x)); }
-// unit u of the triangle's tiling: output frames [8a, 8a + 8) need taps 0 .. 8a + 7, i.e. ceil((8a + 8) / NT) units of NT taps
-template <int NT>
+// unit u of the triangle's tiling: output frames [NO a, NO a + NO) need taps 0 .. NO a + NO - 1, i.e. ceil((NO a + NO) / NT) units of NT taps
+template <int NT, int NO>
 __device__ __forceinline__ bool td_unit(int u, int& a, int& c) {
-    for (a = 0; a < MC_B / 8; a++) {
-        const int n = (8 * a + 8 + NT - 1) / NT;
+    for (a = 0; a < MC_B / NO; a++) {
+        const int n = (NO * a + NO + NT - 1) / NT;
         if (u < n) break;
         u -= n;
     }
     c = u;
-    return a < MC_B / 8;
+    return a < MC_B / NO;
 }
 // taps of a unit (REV: of the reversed tap sequence) from LDS into registers: h1 = {L<-in1, R<-in1}, h2 = {L<-in2, R<-in2}
 template <int NT, bool REV>
@@ -2419,24 +2421,39 @@ __device__ __forceinline__ void td_taps(const float4* s_hc, int c, bool on, v2f 
         h2[jj] = v2f{h.z, h.w};
     }
 }
-// the unit's 8 partial sums {L, R}: xpad = the (possibly reversed) period with TD_PAD zeros in front
-template <int NT>
-__device__ __forceinline__ void td_window(const float2* xpad, int a, int c, v2f (&w)[NT + 7]) {
-    const float2* w0 = xpad + TD_PAD + 8 * a - NT * c - (NT - 1);  // frame of window entry 0 (>= -TD_PAD)
+// the unit's window of the period: xpad = the (possibly reversed) period with TD_PAD zeros in front
+template <int NT, int NO>
+__device__ __forceinline__ void td_window(const float2* xpad, int a, int c, v2f (&w)[NT + NO - 1]) {
+    const float2* w0 = xpad + TD_PAD + NO * a - NT * c - (NT - 1);  // frame of window entry 0 (>= -TD_PAD)
 #pragma unroll
-    for (int q = NT + 6; q >= 0; q--) w[q] = vx_of(w0[q]);  // (in the order of use: tap 0 takes the last eight entries)
+    for (int q = NT + NO - 2; q >= 0; q--) w[q] = vx_of(w0[q]);  // (in the order of use: tap 0 takes the last NO entries)
 }
-template <int NT>
-__device__ __forceinline__ void td_tile(const v2f (&w)[NT + 7], const v2f (&h1)[NT], const v2f (&h2)[NT], v2f (&acc)[8]) {
+// the unit's NO partial sums {L, R}.  A packed multiply-add can follow one on the same accumulator after eight others (measured:
+// 5.8 clocks per instruction with eight chains, 9.1 with four - scripts/probes/pkfma_tile_probe.hip), so four outputs keep
+// the two inputs' sums apart until the end
+template <int NT, int NO>
+__device__ __forceinline__ void td_tile(const v2f (&w)[NT + NO - 1], const v2f (&h1)[NT], const v2f (&h2)[NT], v2f (&acc)[NO]) {
+    v2f acc2[NO];
 #pragma unroll
-    for (int o = 0; o < 8; o++) acc[o] = v2f{0.f, 0.f};
+    for (int o = 0; o < NO; o++) acc[o] = acc2[o] = v2f{0.f, 0.f};
 #pragma unroll
     for (int jj = 0; jj < NT; jj++) {
 #pragma unroll
-        for (int o = 0; o < 8; o++) td_fma_in1(acc[o], h1[jj], w[NT - 1 + o - jj]);
+        for (int o = 0; o < NO; o++) td_fma_in1(acc[o], h1[jj], w[NT - 1 + o - jj]);
 #pragma unroll
-        for (int o = 0; o < 8; o++) td_fma_in2(acc[o], h2[jj], w[NT - 1 + o - jj]);
+        for (int o = 0; o < NO; o++) td_fma_in2(NO < 8 ? acc2[o] : acc[o], h2[jj], w[NT - 1 + o - jj]);
     }
+    if (NO < 8) {
+#pragma unroll
+        for (int o = 0; o < NO; o++) acc[o] += acc2[o];
+    }
+}
+// a unit's sums into the frame's slots
+template <int NO>
+__device__ __forceinline__ void td_store(float2 (*s_pc)[MC_B], int a, int c, const v2f (&acc)[NO]) {
+    float4* dst = reinterpret_cast<float4*>(&s_pc[c][NO * a]);
+#pragma unroll
+    for (int o = 0; o < NO / 2; o++) dst[o] = make_float4(acc[2 * o].x, acc[2 * o].y, acc[2 * o + 1].x, acc[2 * o + 1].y);
 }
 // sum over the wavefront, in every lane: two quad exchanges and two mirrors inside the rows of 16 lanes (DPP: no LDS crossbar
 // round trips as __shfl_xor takes), then the four row sums
@@ -2449,9 +2466,54 @@ __device__ __forceinline__ float td_wave_sum(float v) {
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
-#define TD_NT1 18
-#define TD_NT2 24
+#define TD_NT1 18  // first half: 4 frames x 18 taps, 491 units on the workgroup's 512 threads
+#define TD_NO1 4
+#define TD_NT2 18  // second half: 8 frames x 18 taps, 249 units on the 256 helper threads
+#define TD_NO2 8
+#define TAIL1_THREADS 512
 #define TD_SLOTS ((MC_B + TD_NT1 - 1) / TD_NT1)  // units a frame's sum can have (15; 11 for the second half)
+
+// Threads 256..511 of the tail's workgroup: a unit of each half's direct convolution, and every barrier the others pass until then
+// (a wavefront that has ended no longer counts at a barrier).
+__device__ __forceinline__ void tail1_helper(const TailArgs& A, const float4* s_hc, const float2* s_xp, const float2* s_xr, float2 (*s_pc)[MC_B],
+                                             const int* s_here, const int* s_abort, const int* s_go) {
+    const int tid = threadIdx.x;
+    __syncthreads();  // the taps are in LDS, the first look has been taken
+    if (!A.bell || (s_here[0] && s_here[1] && s_here[2] && s_here[3])) return;  // the period is in place: the frequency-domain form
+    int ua, uc;
+    const bool uon = td_unit<TD_NT1, TD_NO1>(tid, ua, uc);
+    v2f h1r[TD_NT1], h2r[TD_NT1];
+    td_taps<TD_NT1, false>(s_hc, uc, uon, h1r, h2r);
+    __syncthreads();  // the rest's inverse transform
+    const bool inblock = A.predelay > 0 && A.predelay < MC_B;
+#pragma nounroll
+    for (int pass = 0; pass < 2; pass++) {
+        const bool live = pass == 1;
+        if (live && !A.in_gran) {
+            __syncthreads();  // lane 0 has heard the doorbell
+            if (!*s_go) return;
+        }
+        __syncthreads();  // the period is in LDS
+        if (live && *s_abort) return;
+        v2f acc[TD_NO1], win[TD_NT1 + TD_NO1 - 1];
+        td_window<TD_NT1, TD_NO1>(s_xp, uon ? ua : 0, uon ? uc : 0, win);
+        td_tile<TD_NT1, TD_NO1>(win, h1r, h2r, acc);
+        if (uon) td_store<TD_NO1>(s_pc, ua, uc, acc);
+        __syncthreads();  // the units' sums are in LDS
+        if (inblock) __syncthreads();
+    }
+    __syncthreads();  // everyone has read the first half's sums
+    {
+        int a2, c2;
+        const bool on2 = td_unit<TD_NT2, TD_NO2>(tid - MC_B, a2, c2);
+        v2f g1[TD_NT2], g2[TD_NT2], acc[TD_NO2], win[TD_NT2 + TD_NO2 - 1];
+        td_taps<TD_NT2, true>(s_hc, c2, on2, g1, g2);
+        td_window<TD_NT2, TD_NO2>(s_xr, on2 ? a2 : 0, on2 ? c2 : 0, win);
+        td_tile<TD_NT2, TD_NO2>(win, g1, g2, acc);
+        if (on2) td_store<TD_NO2>(s_pc, a2, c2, acc);
+    }
+    __syncthreads();  // the second half's sums are in LDS
+}
 
 __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     const float* in1 = A.in1;
@@ -2493,8 +2555,13 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     __shared__ float4 s_red[4];  // per wave {S1, S2, A1, A2}
     __shared__ int s_abort;      // a parked tail gives up (told to, or the host stayed away)
     __shared__ int s_here[4];    // the period was there at the first look (per wave)
+    __shared__ int s_go;         // doorbell path: the period is there (0: give up)
     __shared__ __align__(16) double s_kq[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid >= MC_B) {  // the second four wavefronts only convolve
+        tail1_helper(A, s_hc, s_xp, s_xr, s_pc, s_here, &s_abort, &s_go);
+        return;
+    }
     const BlockParams& bp = ptab[0];
     const int m = tid;
     const int64_t tau0 = tabs0 * MC_B, tau = tau0 + m, u = tau - predelay;
@@ -2853,7 +2920,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     }
     // ---- the period is still to come
     int ua, uc;  // this thread's unit of the first half
-    const bool uon = td_unit<TD_NT1>(tid, ua, uc);
+    const bool uon = td_unit<TD_NT1, TD_NO1>(tid, ua, uc);
     v2f h1r[TD_NT1], h2r[TD_NT1];
     td_taps<TD_NT1, false>(s_hc, uc, uon, h1r, h2r);
     if (wave == 0) {  // the inverse transform of the rest: the segment without the period's own term
@@ -2881,12 +2948,26 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     }
     __syncthreads();
     const float sc = 1.0f / FFT_N;
-    float pre_lo[2], pre_hi[2];
+    float pre_lo[2];
+    float2* s_hi = reinterpret_cast<float2*>(&s_y[0]);  // the rest's second half, until the period's own term joins it behind the output (s_y has been read)
     {
         const float2 lo = s_fft[m], hi = s_fft[MC_B + m];
-        pre_lo[0] = lo.x * sc, pre_lo[1] = lo.y * sc, pre_hi[0] = hi.x * sc, pre_hi[1] = hi.y * sc;
+        pre_lo[0] = lo.x * sc, pre_lo[1] = lo.y * sc;
+        s_hi[m] = make_float2(hi.x * sc, hi.y * sc);
     }
 
+    // the Q1/Q2 terms of this thread's output sample, as far as they are known: everything but this block's own share (which
+    // only a predelay below one block lets in); what the retired epochs still owe, what the cut at n_ref takes away and the
+    // delayed wet sample itself where it predates this period: one addend per channel
+    const float addl = (u >= tau0 ? 0.f : dwl) + ((ra.x + rb.x) - (td.on ? td_l : 0.f)), addr = (u >= tau0 ? 0.f : dwr) + ((ra.y + rb.y) - (td.on ? td_r : 0.f));
+    const double csg = (u & 1) ? -1.0 : 1.0;
+    const bool cown = corr_on && thi == tabs0;
+    double cbase_l = 0.0, cbase_r = 0.0;
+    if (corr_on) {
+        const double* src = cown ? cprev : ca;
+        cbase_l = (src[0] - cb[0]) + csg * (src[2] - cb[2]);
+        cbase_r = (src[1] - cb[1]) + csg * (src[3] - cb[3]);
+    }
     // ---- the period: pass 0 is the dry run (nothing is waited for, nothing is stored), pass 1 the period's
     float seg_lo[2] = {0.f, 0.f}, own_wet[2] = {0.f, 0.f};
     double cnow[4] = {0, 0, 0, 0};  // the Q1/Q2 prefix sums including this block
@@ -2959,7 +3040,6 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
                 // final for a wave only behind that barrier)
             } else {
                 // Parked: one lane polls the mapped doorbell (a PCIe read per poll), the others wait at the barrier.
-                __shared__ int s_go;
                 if (tid == 0) {
                     int go = 1;
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -3004,8 +3084,8 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         c_fma = 0;
 #endif
         {
-            v2f acc[8], win[TD_NT1 + 7];
-            td_window<TD_NT1>(s_xp, uon ? ua : 0, uon ? uc : 0, win);
+            v2f acc[TD_NO1], win[TD_NT1 + TD_NO1 - 1];
+            td_window<TD_NT1, TD_NO1>(s_xp, uon ? ua : 0, uon ? uc : 0, win);
             // the block's sums {S1, S2, A1, A2} (conv.cu:55-71: what the DC / Nyquist bins of its transform hold), per wave, while
             // the window is on its way from LDS
             {
@@ -3013,16 +3093,12 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
                 const float r0 = td_wave_sum(xin1), r1 = td_wave_sum(xin2), r2 = td_wave_sum(sg * xin1), r3 = td_wave_sum(sg * xin2);
                 if (lane == 0) s_red[wave] = make_float4(r0, r1, r2, r3);
             }
-            td_tile<TD_NT1>(win, h1r, h2r, acc);
+            td_tile<TD_NT1, TD_NO1>(win, h1r, h2r, acc);
 #ifdef MC_JACK_TRACE
-            asm volatile("" ::"v"(acc[0]), "v"(acc[7]));
+            asm volatile("" ::"v"(acc[0]), "v"(acc[TD_NO1 - 1]));
             c_fma = __builtin_amdgcn_s_memtime();
 #endif
-            if (uon) {
-                float4* dst = reinterpret_cast<float4*>(&s_pc[uc][8 * ua]);
-#pragma unroll
-                for (int o = 0; o < 4; o++) dst[o] = make_float4(acc[2 * o].x, acc[2 * o].y, acc[2 * o + 1].x, acc[2 * o + 1].y);
-            }
+            if (uon) td_store<TD_NO1>(s_pc, ua, uc, acc);
         }
         __syncthreads();
 #ifdef MC_JACK_TRACE
@@ -3039,12 +3115,12 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             const float4 q0 = s_red[0], q1 = s_red[1], q2 = s_red[2], q3 = s_red[3];
             const double S1 = (q0.x + q1.x) + (q2.x + q3.x), S2 = (q0.y + q1.y) + (q2.y + q3.y), A1 = (q0.z + q1.z) + (q2.z + q3.z),
                          A2 = (q0.w + q1.w) + (q2.w + q3.w);
-            cnow[0] = cprev[0], cnow[1] = cprev[1], cnow[2] = cprev[2], cnow[3] = cprev[3];
+            cnow[0] = cnow[1] = cnow[2] = cnow[3] = 0.0;  // (this block's terms; the prefix sums are added behind the output)
             if (compat) {
-                cnow[0] += S2 * s_kq[1];
-                cnow[1] += S1 * s_kq[0] + S2 * s_kq[2];
-                cnow[2] += A1 * s_kq[3] + A2 * s_kq[5];
-                cnow[3] += A1 * s_kq[4] + A2 * s_kq[6];
+                cnow[0] = S2 * s_kq[1];
+                cnow[1] = S1 * s_kq[0] + S2 * s_kq[2];
+                cnow[2] = A1 * s_kq[3] + A2 * s_kq[5];
+                cnow[3] = A1 * s_kq[4] + A2 * s_kq[6];
             }
         }
         // a predelay inside the block: the delayed sample is another thread's (not yet visible through global memory)
@@ -3057,26 +3133,19 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         // No global store is issued before the output has left: a barrier drains the vector-memory counter, so every
         // store ahead of it would put its acknowledgement latency on the critical path.
         {
-            float wl = dwl, wr_ = dwr;
+            float wl = 0.f, wr_ = 0.f;
             if (u >= tau0) {
                 wl = inblock ? s_wet[0][u - tau0] : own_wet[0];
                 wr_ = inblock ? s_wet[1][u - tau0] : own_wet[1];
             }
-            wl += ra.x + rb.x;
-            wr_ += ra.y + rb.y;
-            double cl = 0.0, cr = 0.0;
-            if (corr_on) {
-                if (thi == tabs0)
-                    for (int c = 0; c < 4; c++) ca[c] = cnow[c];
-                const double sg = (u & 1) ? -1.0 : 1.0;
-                cl = (ca[0] - cb[0]) + sg * (ca[2] - cb[2]);
-                cr = (ca[1] - cb[1]) + sg * (ca[3] - cb[3]);
+            wl += addl;
+            wr_ += addr;
+            double cl = cbase_l, cr = cbase_r;
+            if (cown) {
+                cl += cnow[0] + csg * cnow[2];
+                cr += cnow[1] + csg * cnow[3];
             }
             const float x1 = xin1, x2 = xin2;
-            if (td.on) {
-                wl -= td_l;
-                wr_ -= td_r;
-            }
             const float vl = fminf(fmaxf((float)((double)wl + cl), -1.f), 1.f);
             const float vr = fminf(fmaxf((float)((double)wr_ + cr), -1.f), 1.f);
             const float yl = vl + x1 * dmix.x + x2 * dmix.y, yr = vr + x1 * dmix.z + x2 * dmix.w;
@@ -3098,7 +3167,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
 #endif
     }
     write_history(td, tau, tabs0, m, xin1, xin2, bp, rc);
-    // ---- behind the output: what later periods need.  Wave 0 transforms the period for the delay line; waves 1-3 sum the
+    // ---- behind the output: what later periods need.  Wave 0 transforms the period for the delay line; the helper threads sum the
     // period's own term of the segment's second half: frame 256 + r takes taps j > r, which is the first half's triangle for the
     // reversed taps and the reversed period (frame 510 - m' of the segment is output m' of that convolution; frame 511 has no term)
     __syncthreads();  // (everyone has read the first half's partial sums)
@@ -3125,18 +3194,6 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             }
             xs_keep[j] = make_float4(x1.x, x1.y, x2.x, x2.y);
         }
-    } else {
-        int a2, c2;
-        const bool on2 = td_unit<TD_NT2>(tid - 64, a2, c2);
-        v2f g1[TD_NT2], g2[TD_NT2], acc[8], win[TD_NT2 + 7];
-        td_taps<TD_NT2, true>(s_hc, c2, on2, g1, g2);
-        td_window<TD_NT2>(s_xr, on2 ? a2 : 0, on2 ? c2 : 0, win);
-        td_tile<TD_NT2>(win, g1, g2, acc);
-        if (on2) {
-            float4* dst = reinterpret_cast<float4*>(&s_pc[c2][8 * a2]);
-#pragma unroll
-            for (int o = 0; o < 4; o++) dst[o] = make_float4(acc[2 * o].x, acc[2 * o].y, acc[2 * o + 1].x, acc[2 * o + 1].y);
-        }
     }
     __syncthreads();
     float seg_hi[2];
@@ -3150,8 +3207,11 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             const float keep = c < nu ? 1.f : 0.f;
             sum += v * keep;
         }
-        seg_hi[0] = pre_hi[0] + sum.x;
-        seg_hi[1] = pre_hi[1] + sum.y;
+        int mh = m;
+        asm volatile("" : "+v"(mh));  // (the address is formed here: kept from in front of the loop it costs the register allocator a spill)
+        const float2 pre_hi = s_hi[mh];
+        seg_hi[0] = pre_hi.x + sum.x;
+        seg_hi[1] = pre_hi.y + sum.y;
     }
     {
         float* cur = seg + (size_t)seg0 * 2 * FFT_N;
@@ -3173,7 +3233,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         }
         if (m == 0) {
             double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
-            for (int c = 0; c < 4; c++) o[c] = cnow[c];
+            for (int c = 0; c < 4; c++) o[c] = cprev[c] + cnow[c];
         }
     }
     // publish completion to the host (mapped pinned memory): all waves drain their stores at the barrier
@@ -3590,7 +3650,11 @@ __device__ __forceinline__ void tail1_body_fft0(const TailArgs& A) {
 #define tail1_body tail1_body_fft0
 #endif
 
-__global__ __launch_bounds__(256) void k_tail1(TailArgs A) { tail1_body(A); }
+#if defined(MCCONV_LAB) && defined(MC_TAIL_FFT0)
+#undef TAIL1_THREADS
+#define TAIL1_THREADS 256
+#endif
+__global__ __launch_bounds__(TAIL1_THREADS) void k_tail1(TailArgs A) { tail1_body(A); }
 
 // The tail of period t (workgroup 0, usually parked on its doorbell) and the streaming sweep over partitions >= 2 of
 // period t + 1 (the other 256 bins x chunks workgroups, one voice) in ONE launch: the sweep pairs only with blocks at
@@ -3612,14 +3676,14 @@ struct SweepArgs {
                        // of its own cost the host a launch per period and, back to back, 5 us of stream time between two tails)
 };
 template <bool UNIFORM>
-__global__ __launch_bounds__(256) void k_jack(TailArgs A, SweepArgs S) {
+__global__ __launch_bounds__(TAIL1_THREADS) void k_jack(TailArgs A, SweepArgs S) {
     if (blockIdx.x == 0) {
         tail1_body(A);
     } else if (S.drop_next && blockIdx.x == gridDim.x - 1) {
         drop_period_fft_body<1>(A.td, S.drop_next, A.tabs0 + 1, A.predelay, A.n_ref, A.ret.b0);
     } else {
         const int w = (int)blockIdx.x - 1;
-        mac_stream_body<UNIFORM, 256, false>(w & (MC_NB - 1), w >> 8, 0, S.H0, S.H1, S.pstride_ir, S.p_begin, S.p_end, S.chunk, S.fdl,
+        mac_stream_body<UNIFORM, TAIL1_THREADS, false>(w & (MC_NB - 1), w >> 8, 0, S.H0, S.H1, S.pstride_ir, S.p_begin, S.p_end, S.chunk, S.fdl,
                                              S.slotgain, S.ring, S.slot0, S.part, S.nsum, S.ch_off, S.ugain, S.inv);
     }
 }

@@ -2424,7 +2424,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
         }
         e->spec_valid = false;
         my_seq = ++e->flag_seq;
-        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front, my_seq, false));
+        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(TAIL1_THREADS), 0, e->stream, tail_args(st_now, pl_now, e->t_front, my_seq, false));
         if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
@@ -2493,9 +2493,9 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
                 e->dspec.buf = S.drop_next;
             }
             if (uni)
-                hipLaunchKernelGGL(k_jack<true>, grid, dim3(256), 0, e->stream, A, S);
+                hipLaunchKernelGGL(k_jack<true>, grid, dim3(TAIL1_THREADS), 0, e->stream, A, S);
             else
-                hipLaunchKernelGGL(k_jack<false>, grid, dim3(256), 0, e->stream, A, S);
+                hipLaunchKernelGGL(k_jack<false>, grid, dim3(TAIL1_THREADS), 0, e->stream, A, S);
             HIP_TRY(hipGetLastError());
             e->pre.valid = true;
             e->pre.pm = 1;
@@ -2547,7 +2547,7 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             if (rc2) return rc2;
         }
         my_seq = ++e->flag_seq;
-        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(256), 0, e->stream, tail_args(st_now, pl_now, e->t_front - 1, my_seq, false));
+        hipLaunchKernelGGL(k_tail1, dim3(1), dim3(TAIL1_THREADS), 0, e->stream, tail_args(st_now, pl_now, e->t_front - 1, my_seq, false));
         if (prep_rc) return prep_rc;
         HIP_TRY(hipGetLastError());
     }
