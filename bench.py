@@ -762,16 +762,17 @@ def main():
             lat = (time.perf_counter() - t1) / n_lat
             # what a JACK client sees: the host idle between periods (500 us here; a real period is 5805 us), the call's own
             # duration counted
-            spaced = 0.0
-            n_sp = 400
+            n_sp = 1000
+            each = []
             for _ in range(n_sp):
                 t1 = time.perf_counter()
                 while (time.perf_counter() - t1) < 500e-6:
                     pass
                 t1 = time.perf_counter()
                 L.mc_process(e._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], BLOCK)
-                spaced += time.perf_counter() - t1
-            spaced /= n_sp
+                each.append(time.perf_counter() - t1)
+            spaced = sum(each) / n_sp
+            spaced_q = np.percentile(np.array(each) * 1e6, [50, 90, 99])
             # a second pass with HIP events around the sweep kernel (the events cost a few us of their own: not in `lat`)
             e.enable_kernel_timing(True)
             e.kernel_stats(reset=True)
@@ -785,6 +786,7 @@ def main():
                 "us_per_block_wall": round(lat * 1e6, 2),
                 "rtf": round(BLOCK / FS / lat, 1),
                 "us_per_call_period_spaced": round(spaced * 1e6, 2),
+                "us_per_call_period_spaced_p50_p90_p99": [round(float(q), 2) for q in spaced_q],
                 "rtf_period_spaced": round(BLOCK / FS / spaced, 1),
                 "avg_runtime_ms": round(e.avgRuntime(), 5),
                 "mac_kernel": "k_mac_stream (every block re-reads 4 IR paths + 2 delay-line inputs: the literal partition x bin MAC)",
@@ -796,7 +798,9 @@ def main():
                 # (not a roofline fraction: the 21 MB a period re-reads come out of L2 / Infinity Cache, and the span excludes dispatch - VERDICT round 2, weak 3)
                 "mac_algorithmic_GBps_over_span_relative_to_hbm_peak": round(ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
                 "note": "all values measured in this run. us_per_block_wall: calls back to back; us_per_call_period_spaced: 500 us idle "
-                        "between calls, as under jackd (the next period's tail is launched one call ahead and parked on a doorbell). "
+                        "between calls, as under jackd (the next period's tail is launched one call ahead and parked; while it waits it "
+                        "finishes every older partition's inverse transform and makes a dry run of the code between the period and its "
+                        "output, and the period's own partition is then a direct convolution on eight wavefronts: kernels.hip.h, tail1_body). "
                         "The "
                         "21 MB working set is re-read every period and is served by L2 / Infinity Cache, not HBM "
                         "(FETCH_SIZE of this launch: profiles/)",
