@@ -2373,6 +2373,10 @@ struct TailArgs {
     // (used only when `bell` is set); out_gran: [2][256] in mapped host memory (null: plain outL / outR + completion word).
     const unsigned long long* in_gran;
     unsigned long long* out_gran;
+    // 256-frame tail: which form a period took, counted in device memory {frequency domain, time domain} (mc_debug_read item 16), and
+    // form != 0 (lab build, MCCONV_TAIL_FORM=td|fd): 1 = always the time-domain form (with its dry run), 2 = always the frequency-domain one
+    unsigned* formcount;
+    int form;
 };
 
 // ---------------------------------------------------------------------------
@@ -2473,13 +2477,18 @@ __device__ __forceinline__ float td_wave_sum(float v) {
 #define TAIL1_THREADS 512
 #define TD_SLOTS ((MC_B + TD_NT1 - 1) / TD_NT1)  // units a frame's sum can have (15; 11 for the second half)
 
+// the first look's verdict (workgroup-uniform: s_here is read behind a barrier)
+__device__ __forceinline__ bool tail1_here(const TailArgs& A, const int* s_here) {
+    if (A.form) return A.form == 2;
+    return !A.bell || (s_here[0] && s_here[1] && s_here[2] && s_here[3]);  // (not parked: the period is in place)
+}
 // Threads 256..511 of the tail's workgroup: a unit of each half's direct convolution, and every barrier the others pass until then
 // (a wavefront that has ended no longer counts at a barrier).
 __device__ __forceinline__ void tail1_helper(const TailArgs& A, const float4* s_hc, const float2* s_xp, const float2* s_xr, float2 (*s_pc)[MC_B],
                                              const int* s_here, const int* s_abort, const int* s_go) {
     const int tid = threadIdx.x;
     __syncthreads();  // the taps are in LDS, the first look has been taken
-    if (!A.bell || (s_here[0] && s_here[1] && s_here[2] && s_here[3])) return;  // the period is in place: the frequency-domain form
+    if (tail1_here(A, s_here)) return;  // the period is in place: the frequency-domain form
     int ua, uc;
     const bool uon = td_unit<TD_NT1, TD_NO1>(tid, ua, uc);
     v2f h1r[TD_NT1], h2r[TD_NT1];
@@ -2489,7 +2498,7 @@ __device__ __forceinline__ void tail1_helper(const TailArgs& A, const float4* s_
 #pragma nounroll
     for (int pass = 0; pass < 2; pass++) {
         const bool live = pass == 1;
-        if (live && !A.in_gran) {
+        if (live && A.bell && !A.in_gran) {
             __syncthreads();  // lane 0 has heard the doorbell
             if (!*s_go) return;
         }
@@ -2719,7 +2728,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         s_here[0] = s_here[1] = s_here[2] = s_here[3] = (unsigned)v == seq && (v >> 32) == 0;
     }
     __syncthreads();
-    const bool here = !A.bell || (s_here[0] && s_here[1] && s_here[2] && s_here[3]);  // (not parked: the period is in place)
+    const bool here = tail1_here(A, s_here);
     if (here) {
         // ---- the period is in place: forward transform, partition 0 in the frequency domain, one inverse transform
         float4* s_x = reinterpret_cast<float4*>(&s_pc[0][0]);  // raw spectra of the new block {X1, X2} (the time-domain form's partial sums are not in use)
@@ -2729,6 +2738,28 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         const unsigned long long c_start = __builtin_amdgcn_s_memtime();
 #endif
+        if (A.form == 2 && A.bell) {  // (lab build: this form forced on a parked tail - wait here, without the ways out a product wait has)
+            if (A.in_gran) {
+                for (;;) {
+                    const unsigned long long g1 = __hip_atomic_load(A.in_gran + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long g2 = __hip_atomic_load(A.in_gran + MC_B + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (__all((unsigned)(g1 >> 32) == seq && (unsigned)(g2 >> 32) == seq)) {
+                        xin1 = __uint_as_float((unsigned)g1);
+                        xin2 = __uint_as_float((unsigned)g2);
+                        break;
+                    }
+                    if ((unsigned)__hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return;  // told to give up
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            } else {
+                for (;;) {
+                    const unsigned long long v = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)v == seq && (v >> 32) != 0) return;  // told to give up
+                    if ((unsigned)v == seq) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+        }
         if (!(A.bell && A.in_gran)) {  // (tagged granules were read by the look)
             if (A.bell) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the period was written before the doorbell
             // (system scope: the period may sit in device memory the CPU wrote through the BAR - not to be served from a cache)
@@ -2898,6 +2929,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             if (m == 0) {
                 double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
                 for (int c = 0; c < 4; c++) o[c] = s_c[c];
+                if (A.formcount) A.formcount[0] += 1;  // (one tail at a time per engine)
             }
         }
         // publish completion to the host (see the end of the function)
@@ -2977,7 +3009,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
 #pragma nounroll
     for (int pass = 0; pass < 2; pass++) {
         const bool live = pass == 1;
-        if (live) {
+        if (live && A.bell) {  // (not parked - this form forced in a lab build: the period is in place)
             if (A.in_gran) {
                 // Parked, tagged input: every lane looks at its own two granules of the period; lane 0 also watches the doorbell word for
                 // the "give up" command and the park time.  THREE looks are in flight, a third of a round trip through memory apart
@@ -3068,7 +3100,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         c_start = __builtin_amdgcn_s_memtime();
 #endif
         // (system scope: the period may sit in device memory the CPU wrote through the BAR - not to be served from a cache)
-        if (live && !A.in_gran) {  // (tagged granules are read by the looks above)
+        if (live && !(A.bell && A.in_gran)) {  // (tagged granules are read by the looks above)
             xin1 = __hip_atomic_load(in1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             xin2 = __hip_atomic_load(in2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -3234,6 +3266,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         if (m == 0) {
             double* o = cring + (size_t)(tabs0 & (rc - 1)) * 4;
             for (int c = 0; c < 4; c++) o[c] = cprev[c] + cnow[c];
+            if (A.formcount) A.formcount[1] += 1;
         }
     }
     // publish completion to the host (mapped pinned memory): all waves drain their stores at the barrier

@@ -293,6 +293,8 @@ struct mc_engine {
     unsigned* hd_exited = nullptr;
     // how often a parked period was used / gave up on its own (host away > park_ms) / was told to give up: mc_debug_read item 6
     uint64_t n_park_hit = 0, n_park_timeout = 0, n_park_cancel = 0;
+    unsigned* d_tailform = nullptr;  // 256-frame tails by the form partition 0 took {frequency domain, time domain}, counted by the kernel (mc_debug_read item 16)
+    int tail_form = 0;               // lab build, MCCONV_TAIL_FORM=td|fd: one form for every 256-frame tail (0: the first look decides)
     uint64_t n_drop_carried = 0;  // JACK path, Q8 regime: periods whose cut terms came with the launch before theirs (mc_debug_read item 9, fourth word)
     uint64_t n_mac_form[3] = {0, 0, 0};  // batches whose partition sums took the fused / split second-level transform / the resident MAC (mc_debug_read item 10)
     uint64_t n_drop_fft = 0, n_drop_ahead = 0, n_drop_tiles = 0;  // Q8 regime: batches by the form their cut terms took (mc_debug_read item 9)
@@ -2358,6 +2360,8 @@ int process_one(mc_engine* e, const float* in1, const float* in2, float* outL, f
             } else
                 A.drop = launch_drop_period(e, A.td, blk, st.ctx.predelay);  // (queued ahead of the tail this argument block is for)
         }
+        A.formcount = e->d_tailform;
+        A.form = e->tail_form;
         A.in_gran = e->tio ? reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(e->d_bar) + 16384) : nullptr;
         A.out_gran = e->tio ? e->hd_gran : nullptr;
         return A;
@@ -3172,6 +3176,9 @@ int mc_create(const mc_config* cfg, mc_engine** out) {
     for (int i = 0; i < 4; i++) ENG_TRY(hipMalloc(&e->d_io[i], sizeof(float) * (size_t)e->Thost * MC_B));
     ENG_TRY(hipHostMalloc(&e->h_io, sizeof(float) * 4 * (size_t)e->Thost * MC_B, hipHostMallocMapped));
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_io, e->h_io, 0));
+    ENG_TRY(hipMalloc(&e->d_tailform, 2 * sizeof(unsigned)));
+    ENG_TRY(hipMemset(e->d_tailform, 0, 2 * sizeof(unsigned)));
+    if (const char* f = LAB_ENV("MCCONV_TAIL_FORM")) e->tail_form = !std::strcmp(f, "td") ? 1 : !std::strcmp(f, "fd") ? 2 : 0;
     ENG_TRY(hipHostMalloc(&e->h_flag, 256, hipHostMallocMapped));  // completion word, doorbell, "gave up" word: a line each
     ENG_TRY(hipHostGetDevicePointer((void**)&e->hd_flag, e->h_flag, 0));
     std::memset(e->h_flag, 0, 256);
@@ -3346,6 +3353,7 @@ void mc_destroy(mc_engine* e) {
     if (e->d_bar) (void)hipFree(e->d_bar);
     if (e->h_gran) (void)hipHostFree(e->h_gran);
     if (e->h_io) (void)hipHostFree(e->h_io);
+    if (e->d_tailform) (void)hipFree(e->d_tailform);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     for (int i = 0; i < kStageBufs; i++) {
         if (e->h_ptab[i]) {
@@ -3780,6 +3788,18 @@ int mc_debug_read(mc_engine* e, int which, uint64_t idx, void* dst, uint64_t off
     if (which == 9) {  // Q8 regime, batches: {cut terms summed by k_drop_fft for the whole batch, by the forward transforms (k_fwd<true>), in the time domain}: no stream access
         const uint64_t c[4] = {e->n_drop_fft, e->n_drop_ahead, e->n_drop_tiles, e->n_drop_carried};
         if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
+        std::memcpy(dst, reinterpret_cast<const char*>(c) + off, bytes);
+        return MC_OK;
+    }
+    if (which == 16) {  // 256-frame tails by the form their partition 0 took {frequency domain, time domain}: counted on the device, read behind the stream
+        unsigned c[2] = {0, 0};
+        if (off + bytes > sizeof(c)) return fail(MC_ERR_ARG, "read beyond the counters");
+        if (e->d_tailform) {
+            int rc = leave_jack_path(e);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpy(c, e->d_tailform, sizeof(c), hipMemcpyDeviceToHost));
+        }
         std::memcpy(dst, reinterpret_cast<const char*>(c) + off, bytes);
         return MC_OK;
     }

@@ -261,6 +261,14 @@ class Convolution:
         check(self._L.mc_debug_read(self._h, 6, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
         return dict(used=int(a[0]), timed_out=int(a[1]), cancelled=int(a[2]))
 
+    def tail_forms(self):
+        """JACK path, 256-frame periods: tails by the form partition 0 took - frequency domain (the period was already there when
+        the tail looked: calls back to back, periods launched on arrival) or time domain (a parked tail that had to wait).
+        Counted by the kernel (mc_debug_read item 16; leaves the JACK path and waits for the stream)."""
+        a = np.zeros(2, np.uint32)
+        check(self._L.mc_debug_read(self._h, 16, 0, a.ctypes.data_as(C.c_void_p), 0, a.nbytes, None))
+        return dict(frequency_domain=int(a[0]), time_domain=int(a[1]))
+
     def drop_stats(self):
         """Q8 regime: batches by the form their cut terms took (mc_debug_read item 9; host-side counters)."""
         a = np.zeros(4, np.uint64)

@@ -234,7 +234,8 @@ uint64_t mc_preferred_batch(const mc_engine *e, uint64_t at_most);
  * launch before theirs (4 x uint64), 10 = batch launches by the form
  * of their partition sums {fused, split second-level transform, resident MAC} (3 x uint64), 11 = overlap-save form {batches that
  * took it, builds of its spectra} (2 x uint64), 12 / 13 / 14 = its row buffer and spectra (float4), 15 = 1 when the library is the lab
- * build (-DMCCONV_LAB: measurement switches and alternative kernels).  dims[0..3] receive
+ * build (-DMCCONV_LAB: measurement switches and alternative kernels), 16 = 256-frame JACK tails by the form partition 0 took
+ * {frequency domain, time domain}, counted by the kernel (2 x uint32; read behind the stream).  dims[0..3] receive
  * {pstride, ring, max_batch, wet ring length} when non-null. */
 int mc_debug_read(mc_engine *e, int which, uint64_t idx, void *dst, uint64_t offset_bytes, uint64_t bytes,
                   uint64_t dims[4]);

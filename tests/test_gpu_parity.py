@@ -2502,7 +2502,15 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
             c.prepare(i, ir)
         apply_params(c, p0, p1, False)
         outs.append(stream(c, with_pauses=park))
+        forms = c.tail_forms()
         c.close()
+        if period == 256 and not os.environ.get("MCCONV_LIB"):
+            # both forms of the 256-frame tail ran: a parked tail that had to wait takes partition 0 in the time domain, a period
+            # launched on arrival (every one of them with MCCONV_NO_PARK=1) in the frequency domain
+            if park and not any(os.environ.get(k) for k in ("MCCONV_NO_SPECULATE", "MCCONV_NO_SPIN", "MCCONV_NO_PARK")):
+                assert forms["time_domain"] >= 30 and forms["frequency_domain"] >= 20, forms
+            else:
+                assert forms["time_domain"] == 0 and forms["frequency_domain"] == ncalls, forms
         if park and not any(os.environ.get(k) for k in ("MCCONV_NO_SPECULATE", "MCCONV_NO_SPIN")):  # (those switches leave nothing parked)
             # the paths under test really ran: parked periods were used before the first pause, a pause made one time out,
             # the controller / batch / reload told parked periods to give up, and parking resumed after the second settling
