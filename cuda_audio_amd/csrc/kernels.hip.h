@@ -2738,7 +2738,8 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         const unsigned long long c_start = __builtin_amdgcn_s_memtime();
 #endif
-        if (A.form == 2 && A.bell) {  // (lab build: this form forced on a parked tail - wait here, without the ways out a product wait has)
+        if (A.form == 2 && A.bell) {  // (lab build: this form forced on a parked tail - wait here)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             if (A.in_gran) {
                 for (;;) {
                     const unsigned long long g1 = __hip_atomic_load(A.in_gran + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2749,6 +2750,10 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
                         break;
                     }
                     if ((unsigned)__hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return;  // told to give up
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {  // (every wave comes here within a poll of the others)
+                        if (tid == 0) __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
             } else {
@@ -2756,6 +2761,10 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
                     const unsigned long long v = __hip_atomic_load(A.bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((unsigned)v == seq && (v >> 32) != 0) return;  // told to give up
                     if ((unsigned)v == seq) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > A.park_ticks) {
+                        if (tid == 0) __hip_atomic_store(A.exited, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
                     __builtin_amdgcn_s_sleep(4);
                 }
             }
