@@ -800,7 +800,7 @@ def main():
                 "note": "all values measured in this run. us_per_block_wall: calls back to back; us_per_call_period_spaced: 500 us idle "
                         "between calls, as under jackd (the next period's tail is launched one call ahead and parked; while it waits it "
                         "finishes every older partition's inverse transform and makes a dry run of the code between the period and its "
-                        "output, and the period's own partition is then a direct convolution on eight wavefronts: kernels.hip.h, tail1_body). "
+                        "output, and the period's own partition is then a direct convolution on eight wavefronts: csrc/jack_tail.hip.h, tail1_body). "
                         "The "
                         "21 MB working set is re-read every period and is served by L2 / Infinity Cache, not HBM "
                         "(FETCH_SIZE of this launch: profiles/)",

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mcconv.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("kernels.hip.h", "fft512.hip.h", "ossave.hip.h", "singlefft.hip.h", "singlefft_host.hip.h", "params_handoff.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("kernels.hip.h", "jack_tail.hip.h", "fft512.hip.h", "ossave.hip.h", "singlefft.hip.h", "singlefft_host.hip.h", "params_handoff.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "mcconv.h")]
 OUT = os.path.join(HERE, "libmcconv.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -2424,7 +2424,7 @@ def test_parked_periods_survive_pauses_and_interleaved_calls(oracle_mod, gpu_lib
     a controller change, a batch call and an IR reload tell the parked period to give up; the samples are the oracle's
     throughout.  MCCONV_NO_PARK=1 (every period launched on arrival) gives the same samples to rounding: since round 4 a
     256-frame period that has to be waited for takes partition 0 in the time domain, one that is already there in the frequency
-    domain (kernels.hip.h, tail1_body); the 512-frame path has one form and gives the same bits."""
+    domain (csrc/jack_tail.hip.h, tail1_body); the 512-frame path has one form and gives the same bits."""
     import time
 
     from cuda_audio_amd.synth import make_input, make_ir
