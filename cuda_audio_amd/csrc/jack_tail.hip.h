@@ -1514,6 +1514,27 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
             rb[j] = retired_at(ret.fix, ret.rr, tau);
         }
     }
+    // 512-frame periods: the low partitions' spectra and the old blocks' slot gains are requested here, with everything else (behind the
+    // forward transforms' barrier, where they are used, their round trip through memory would sit between the period and its output;
+    // at 1024 frames the 176 registers they would hold across the wait are not there)
+    constexpr bool EARLY_H = PM == 2;
+    float4 h0e[EARLY_H ? MC_MAXV : 1][PM], h1e[EARLY_H ? MC_MAXV : 1][PM], golde[EARLY_H ? MC_MAXV : 1][PM];
+    if constexpr (EARLY_H) {
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXV; vi++) {
+#pragma unroll
+            for (int p = 0; p < PM; p++) h0e[vi][p] = h1e[vi][p] = golde[vi][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vi < vset.n) {
+#pragma unroll
+                for (int p = 0; p < PM; p++) {
+                    h0e[vi][p] = vset.H0[vi][(size_t)tid * pstride_ir + p];
+                    h1e[vi][p] = vset.H1[vi][(size_t)tid * pstride_ir + p];
+                }
+#pragma unroll
+                for (int q = 1; q < PM; q++) golde[vi][q] = slotgain[(size_t)vset.vid[vi] * ring + ((slot0 - q) & (ring - 1))];
+            }
+        }
+    }
     double cprev[4] = {0, 0, 0, 0};
     if (tid == 0 && tabs0 > 0) {
         const double* pp = cring + (size_t)((tabs0 - 1) & (rc - 1)) * 4;
@@ -1647,13 +1668,18 @@ __global__ __launch_bounds__(256) void k_tailp(const float* __restrict__ in1, co
             const int row = vset.vid[vi];
             const float* gn = ptab->g[row];
             float4 h0[PM], h1[PM], gold[PM];
+            if constexpr (EARLY_H) {
 #pragma unroll
-            for (int p = 0; p < PM; p++) {
-                h0[p] = vset.H0[vi][(size_t)k * pstride_ir + p];
-                h1[p] = vset.H1[vi][(size_t)k * pstride_ir + p];
+                for (int p = 0; p < PM; p++) h0[p] = h0e[vi][p], h1[p] = h1e[vi][p], gold[p] = golde[vi][p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < PM; p++) {
+                    h0[p] = vset.H0[vi][(size_t)k * pstride_ir + p];
+                    h1[p] = vset.H1[vi][(size_t)k * pstride_ir + p];
+                }
+#pragma unroll
+                for (int q = 1; q < PM; q++) gold[q] = slotgain[(size_t)row * ring + ((slot0 - q) & (ring - 1))];
             }
-#pragma unroll
-            for (int q = 1; q < PM; q++) gold[q] = slotgain[(size_t)row * ring + ((slot0 - q) & (ring - 1))];
 #pragma unroll
             for (int j = 0; j < PM; j++) {
 #pragma unroll
