@@ -5,15 +5,11 @@
 #pragma once
 
 // ---------------------------------------------------------------------------
-// Single-block (JACK) path.  k_mac_stream sums partitions p >= 1, which depend
-// only on blocks already in the delay line; this kernel does everything that
-// needs the new block, in one workgroup:
-//   wave 0: forward transform of the block (read straight from mapped host
-//           memory), delay-line slot, S/A sums          | waves 1-3: add the chunk partials
-//   all   : p = 0 term  g_v H_{v,.,0} (x) X[t]  and p = 1 term  g_v(t-1) H_{v,.,1} (x) X[t-1]  for the 256 bins and every voice
-//   wave 0: packed inverse transform
-//   all   : overlap-add with the previous tail, Q1/Q2 prefix update, predelay,
-//           Q8, clamp, dry mix, output straight to mapped host memory.
+// Single-block (JACK) path.  k_mac_stream sums partitions p >= 2, which depend only on blocks at least two periods old; the tail
+// (tail1_body below, one workgroup) does everything that needs the new block or the previous one: the p = 1 term against the previous
+// block's spectrum, the p = 0 term against the new block - in the time domain when the tail had to wait for the period, in the
+// frequency domain when the period was already there -, overlap-add with the previous segment, Q1/Q2 prefix update, predelay, Q8,
+// clamp, dry mix, the output as tagged granules to mapped host memory; then the block's spectrum for the delay line.
 // Replaces, for nframes = 256, the whole body of onProcess (conv.cu:321-451).
 // ---------------------------------------------------------------------------
 struct VoiceSet {
@@ -90,7 +86,7 @@ struct TailArgs {
 // each.  Second half (frames 256 + r: taps j > r), behind the output: the same triangle with both sequences reversed, 8 frames x
 // 18 taps, 249 units on the helper threads while wave 0 transforms the period for the delay line.
 // ---------------------------------------------------------------------------
-#define TD_PAD 32  // zeros in front of the period in LDS (a unit's window starts up to NT + 6 frames before frame 0)
+#define TD_PAD 32  // zeros in front of the period in LDS (a unit's window starts up to NT + NO - 2 frames before frame 0)
 __device__ __forceinline__ void td_fma_in1(v2f& acc, v2f h, v2f x) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(h), "v"(x)); }
 __device__ __forceinline__ void td_fma_in2(v2f& acc, v2f h, v2f x) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(h), "v"(x)); }
 // unit u of the triangle's tiling: output frames [NO a, NO a + NO) need taps 0 .. NO a + NO - 1, i.e. ceil((NO a + NO) / NT) units of NT taps
@@ -166,7 +162,7 @@ __device__ __forceinline__ float td_wave_sum(float v) {
 #define TD_NT2 18  // second half: 8 frames x 18 taps, 249 units on the 256 helper threads
 #define TD_NO2 8
 #define TAIL1_THREADS 512
-#define TD_SLOTS ((MC_B + TD_NT1 - 1) / TD_NT1)  // units a frame's sum can have (15; 11 for the second half)
+#define TD_SLOTS ((MC_B + TD_NT1 - 1) / TD_NT1)  // units a frame's sum can have (15 in either half)
 
 // the first look's verdict (workgroup-uniform: s_here is read behind a barrier)
 __device__ __forceinline__ bool tail1_here(const TailArgs& A, const int* s_here) {
@@ -398,7 +394,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
     // A first look for the period decides the form of the rest.
     // NOT THERE (the host idles between periods, as under jackd): there is time - the rest's inverse transform is done now, and then
     // a DRY RUN of everything between the period and its output.  That stretch is straight-line code executed once per launch, and
-    // from an instruction cache that every launch starts cold it runs at 8-12 clocks per instruction (s_memtime stamps: 288 packed
+    // from an instruction cache that every launch starts cold it runs at 8-12 clocks per instruction (s_memtime stamps, four wavefronts: 288 packed
     // multiply-adds 2400 clocks, the whole stretch 4500); the second time, 1.4 us sooner, it comes out of the cache.
     // ALREADY THERE (calls back to back, or a period launched on arrival): nothing can be prepared, every instruction is fetched
     // cold, and what counts is how many there are until the kernel ends: the frequency-domain form below (partition 0 as one more
