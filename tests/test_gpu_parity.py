@@ -2708,3 +2708,49 @@ def test_random_mix_of_batch_lengths_and_single_periods(oracle_mod, gpu_lib, see
     assert np.abs(want).max() < 1.0  # (the wet sum stays inside the clamp: Q4)
     err = rms(got - want)
     assert err <= RMS_TOL, f"seed {seed}: rms {err:.3e} (signal {rms(want):.3e}), calls {len(sizes)}"
+
+
+@pytest.mark.parametrize("case", ["plain", "predelay_inside_the_block", "predelay_of_two_blocks", "q8_regime", "two_irs"])
+def test_spaced_jack_periods_take_the_time_domain_tail_and_match_the_oracle(oracle_mod, gpu_lib, case):
+    """256-frame periods with the host away between calls (1 ms here; jackd: 5.8 ms): once the cross-fade has settled every period is
+    parked a call ahead, the parked tail finds no period at its first look, finishes the older partitions' inverse transform, makes its
+    dry run and waits - partition 0 is then the direct convolution on eight wavefronts (csrc/jack_tail.hip.h, tail1_body / tail1_helper).
+    The device-side count (Convolution.tail_forms) says that this form ran for the spaced calls; the samples are the oracle's: with a
+    predelay inside the block (the delayed sample is another thread's), of two blocks, in the Q8 regime (cut terms carried by the launch
+    before), and with a different IR on each input."""
+    import time
+
+    from cuda_audio_amd.synth import make_input, make_ir
+
+    if any(os.environ.get(k) for k in ("MCCONV_NO_PARK", "MCCONV_NO_SPIN", "MCCONV_NO_SPECULATE")) or os.environ.get("MCCONV_TAIL_FORM") == "fd":
+        pytest.skip("nothing is parked / one form is forced under this switch")
+    n_ref, settle, spaced = 4096, 200, 120
+    compat = True
+    taps = n_ref - 1024 if case == "q8_regime" else 2500
+    irs = [make_ir(taps, seed=71, norm=0.05), make_ir(taps - 300, seed=73, norm=0.05)]
+    pd = {"plain": 0, "predelay_inside_the_block": 100, "predelay_of_two_blocks": 512, "q8_regime": 1024, "two_irs": 64}[case]
+    p0 = dict(BASE, select=0, predelay=pd, wet=0.6)
+    p1 = dict(BASE, select=1 if case == "two_irs" else 0, predelay=pd, level=0.9)
+    total = (settle + spaced) * 256
+    x = make_input(total, seed=77)
+    ref = oracle_mod.RefCompat(n_ref, compat)
+    c = _conv(fftSize=n_ref, max_batch=8, compat=compat)
+    for i, ir in enumerate(irs):
+        ref.prepare(i, ir)
+        c.prepare(i, ir)
+    apply_params(ref, p0, p1, True)
+    apply_params(c, p0, p1, False)
+    want = ref.process(x[0], x[1], block=256)
+    got = np.zeros((2, total), np.float32)
+    for b in range(settle + spaced):
+        if b >= settle:
+            time.sleep(0.001)
+        s = slice(b * 256, (b + 1) * 256)
+        got[:, s] = np.stack(c.onProcess(x[0, s], x[1, s]))
+    forms, parked = c.tail_forms(), c.park_stats()
+    c.close()
+    assert rms(got - want) <= RMS_TOL, rms(got - want)
+    assert rms(got[:, settle * 256:] - want[:, settle * 256:]) <= RMS_TOL
+    if os.environ.get("MCCONV_TAIL_FORM") != "td":
+        assert parked["used"] >= spaced - 2 and forms["time_domain"] >= spaced - 2, (forms, parked)
+    assert forms["time_domain"] + forms["frequency_domain"] == settle + spaced, forms
