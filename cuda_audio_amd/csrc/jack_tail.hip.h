@@ -422,8 +422,7 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
         __shared__ double s_c[4];
         __shared__ float4 s_sa;
 #ifdef MC_JACK_TRACE
-        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long c_start = __builtin_amdgcn_s_memtime();
+        unsigned long long t_start = 0, c_start = 0;
 #endif
         if (A.form == 2 && A.bell) {  // (lab build: this form forced on a parked tail - wait here)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -462,9 +461,16 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             xin1 = __hip_atomic_load(in1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             xin2 = __hip_atomic_load(in2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        float4 xs_keep[4];  // wave 0: the block's spectra, stored to the delay line at the end of the kernel
+#ifdef MC_FD_WARM  // (measurement build: what the frequency-domain form would take out of a warm instruction cache - a dry pass first)
+#pragma nounroll
+        for (int fdpass = 0; fdpass < 2; fdpass++) {
+#endif
+#ifdef MC_JACK_TRACE
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start), "=s"(c_start) : "v"(xin1));  // (in program order: per trip of the loop)
+#endif
         s_xp[TD_PAD + tid] = make_float2(xin1, xin2);
         __syncthreads();
-        float4 xs_keep[4];  // wave 0: the block's spectra, stored to the delay line at the end of the kernel
         if (wave == 0) {
             float2 v[8];
 #pragma unroll
@@ -550,6 +556,9 @@ __device__ __forceinline__ void tail1_body(const TailArgs& A) {
             for (int c = 0; c < 4; c++) s_c[c] = cprev[c] + d[c];
         }
         __syncthreads();
+#ifdef MC_FD_WARM
+        }
+#endif
         // No global store is issued before the output has left: a barrier drains the vector-memory counter, so every
         // store ahead of it would put its acknowledgement latency on the critical path.
         float seg_lo[2], seg_hi[2], own_wet[2];

@@ -30,7 +30,7 @@
 #include "fft512.hip.h"
 
 #if !defined(MCCONV_LAB) && (defined(G2_ABL) || defined(G2_STAMPS) || defined(G2_ALIAS_TEST) || defined(DF_DBG) || defined(DF_LINEAR) || \
-                             defined(TAILP_VGPR_CAP) || defined(IW_LINEAR_TILES) || defined(OS_ABL) || defined(OS_OUT_UNROLL) || defined(MC_JACK_TRACE))
+                             defined(TAILP_VGPR_CAP) || defined(IW_LINEAR_TILES) || defined(OS_ABL) || defined(OS_OUT_UNROLL) || defined(MC_JACK_TRACE) || defined(MC_FD_WARM) || defined(MC_TAIL_FFT0))
 #error "the measurement builds (timing ablations, time stamps, traces) are part of the lab build only: add -DMCCONV_LAB"
 #endif
 #define MC_B 256
